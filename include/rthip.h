@@ -1,0 +1,247 @@
+/*
+ * rthip.h — C-ABI of the MI355X (gfx950) Raycast hot path.
+ *
+ * This is the drop-in boundary below re::AbstractRaycaster (reference Raytracer/Raytracer.h:55-98):
+ * a HIP-backed subclass (raytracing_amd/host: re::HipRaytracer) flattens the compiled scene into
+ * the POD blobs below at render start and calls these entry points from its detached render
+ * thread, exactly where the reference spawns its DoRaytraceThread workers
+ * (Raytracer/Raytracer.cpp:39-87).  Plain C: pointers and sizes only, no C++/torch types.
+ * Every call returns 0 on success and a negative rthip_status on failure;
+ * rthip_last_error() returns the message of the calling thread's last failure.
+ *
+ * All reals are IEEE double in the reference's operation order (typedef double real,
+ * Raytracer/Common.h:7); the kernels are built with -ffp-contract=off.
+ */
+#ifndef RTHIP_H
+#define RTHIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rthip_ctx rthip_ctx;
+
+enum rthip_status {
+    RTHIP_OK = 0,
+    RTHIP_E_INVALID = -1,     /* bad argument / inconsistent scene description */
+    RTHIP_E_HIP = -2,         /* a HIP runtime call failed (no device, OOM, launch failure) */
+    RTHIP_E_UNSUPPORTED = -3, /* scene uses a feature outside the device path (limits below) */
+    RTHIP_E_INTERRUPTED = -4, /* rthip_interrupt() was called during the render */
+    RTHIP_E_STATE = -5        /* call order (render before upload, ...) */
+};
+
+enum { RTHIP_SHAPE_SPHERE = 0, RTHIP_SHAPE_PLANE = 1, RTHIP_SHAPE_MESH = 2 };
+enum { RTHIP_LIGHT_DIRECTIONAL = 0, RTHIP_LIGHT_AMBIENT = 1, RTHIP_LIGHT_POINT = 2 }; /* Scene.h:17 */
+enum { RTHIP_NOISE_CHECKER = 0, RTHIP_NOISE_PERLIN = 1, RTHIP_NOISE_WORLEY = 2, RTHIP_NOISE_MARBLE = 3 };
+enum { RTHIP_BG_NONE = 0, RTHIP_BG_COLOR = 1, RTHIP_BG_SKYBOX = 2 };
+enum { RTHIP_MAT_UNIFORM = 0, RTHIP_MAT_INTERP = 1 };
+enum { RTHIP_RENDER_RAYTRACER = 0, RTHIP_RENDER_DEBUG_NORMAL = 1, RTHIP_RENDER_DEBUG_COLOR = 2 };
+
+#define RTHIP_MAX_RECURSION 16   /* Raytracer::MaxRecursion upper bound on the device */
+#define RTHIP_MAX_MAT_STACK 8    /* max nesting of InterpolatedMaterial trees */
+#define RTHIP_KD_MAX_DEPTH 100   /* KDTreeTriangle depth cap, Scene.cpp:25 */
+
+/* One scene-graph node that carries a Shape, in pre-order (Scene::CastRayRecursive visits
+ * nodes in this order and the first node wins distance ties, Scene.cpp:217-233).
+ * Matrices are the first three rows (row-major 3x4) of Transform's m_Transform,
+ * m_InverseTransform and m_NormalTransform (Scene.cpp:261-263) as computed on the host. */
+typedef struct {
+    int32_t type;        /* RTHIP_SHAPE_* */
+    int32_t material;    /* index into rthip_scene_desc.materials (root op of the shape's Material) */
+    int32_t mesh;        /* index into meshes[] for RTHIP_SHAPE_MESH, else -1 */
+    uint32_t shape_id;   /* Shape::GetID() (Scene.h:137), reported back in out_shape_id */
+    double inv[12];      /* world -> local */
+    double fwd[12];      /* local -> world */
+    double nrm[12];      /* normal transform */
+    double plane_n[4];   /* Plane::Normal (un-normalised, Scene.h:159); [3] unused */
+} rthip_shape;
+
+/* kd-tree node, 16 bytes.  Nodes of one mesh are stored in pre-order; the left child of an
+ * interior node i (if present) is i+1.  split = the plane BoundingBox::Split was called with
+ * (Scene.cpp:56).  Interior: link = index of the right child (mesh-relative), info = axis |
+ * HAS_LEFT | HAS_RIGHT.  Leaf: link = first entry in kd_refs (mesh-relative), info = LEAF |
+ * (count << 8). */
+typedef struct {
+    double split;
+    uint32_t link;
+    uint32_t info;
+} rthip_kdnode;
+#define RTHIP_KD_AXIS_MASK 0x3u
+#define RTHIP_KD_HAS_LEFT 0x4u
+#define RTHIP_KD_HAS_RIGHT 0x8u
+#define RTHIP_KD_LEAF 0x10u
+#define RTHIP_KD_COUNT_SHIFT 8
+
+/* Per-triangle record tested by Mesh::IntersectTriangle (Scene.cpp:421-467): the values
+ * Triangle::Update caches (Scene.cpp:509-523).  128 bytes, 128-byte aligned in HBM. */
+typedef struct {
+    double v0[3];
+    double face_normal[3];
+    double e0[3];   /* v1 - v0 */
+    double e1[3];   /* v2 - v0 */
+    double d00, d01, d11, inv_den;
+} rthip_tri;
+
+typedef struct {
+    uint32_t node_base, node_count;   /* into kd_nodes / kd_bounds */
+    uint32_t ref_base, ref_count;     /* into kd_refs (values are mesh-relative triangle indices) */
+    uint32_t tri_base, tri_count;     /* into tris / tri_normals */
+    int32_t normal_mode;              /* 0 Face, 1 Vertex (Scene.h:18) */
+    uint32_t max_depth;               /* deepest node, sizes the traversal stack */
+} rthip_mesh;
+
+/* Material trees in postfix order: UNIFORM pushes (color, absorptance); INTERP pops b then a and
+ * pushes Lerp(a, b, noise.Sample(p)) (Material.cpp:21-29).  A shape's material index points at
+ * the LAST op of its tree; first_op = index of the first op of that tree. */
+typedef struct {
+    int32_t op;          /* RTHIP_MAT_* */
+    int32_t noise;       /* INTERP: index into noises */
+    int32_t first_op;    /* first op of the subtree ending here */
+    int32_t pad;
+    double color[3];     /* UNIFORM: absorbed colour */
+    double absorptance;  /* UNIFORM */
+} rthip_matop;
+
+typedef struct {
+    int32_t type;          /* RTHIP_NOISE_* */
+    int32_t table;         /* PERLIN/MARBLE: index into perlin_tables (units of 256 bytes) */
+    int32_t points_base;   /* WORLEY: first point in worley_points (units of 3 doubles) */
+    int32_t divisions;     /* WORLEY */
+    uint32_t octaves;      /* PERLIN/MARBLE (Perlin.h:24), 1..8 */
+    int32_t pad;
+    double domain;         /* Noise::m_DomainSize */
+    double persistance;    /* Perlin.h:23 */
+    double step;           /* Worley.h:21 = 1.0 / divisions */
+    double frequency;      /* Marble.h:16 */
+    double turbolence;     /* Marble.h:16 */
+} rthip_noise;
+
+typedef struct {
+    int32_t type;      /* RTHIP_LIGHT_* */
+    int32_t enabled;
+    double direction[3];
+    double position[3];
+    double color[3];
+    double attenuation;
+} rthip_light;
+
+typedef struct {
+    int32_t type;        /* RTHIP_BG_* */
+    int32_t table;       /* SKYBOX: perlin table index of SkyBox::m_Perlin (domain 1) */
+    int32_t sun_light;   /* SKYBOX: index into lights or -1 (m_Sun == nullptr) */
+    int32_t pad;
+    double color0[3];    /* COLOR: m_Color; SKYBOX: m_SkyColor0 */
+    double color1[3];    /* SKYBOX: m_SkyColor1 */
+} rthip_background;
+
+/* The flattened scene.  All arrays are host memory owned by the caller; rthip_upload_scene
+ * copies them to the device (and keeps nothing pointing into them). */
+typedef struct {
+    const rthip_shape *shapes;          uint32_t n_shapes;
+    const rthip_mesh *meshes;           uint32_t n_meshes;
+    const rthip_kdnode *kd_nodes;       uint64_t n_kd_nodes;
+    const double *kd_bounds;            /* n_kd_nodes * 6: Min xyz, Max xyz (KDTreeTriangle::Bounds) */
+    const uint32_t *kd_refs;            uint64_t n_kd_refs;
+    const rthip_tri *tris;              uint64_t n_tris;
+    const double *tri_normals;          /* n_tris * 9: Triangle::Normals */
+    const rthip_matop *materials;       uint32_t n_materials;
+    const rthip_noise *noises;          uint32_t n_noises;
+    const uint8_t *perlin_tables;       uint32_t n_perlin_tables;   /* n * 256 bytes */
+    const double *worley_points;        uint64_t n_worley_points;   /* n * 3 doubles */
+    const rthip_light *lights;          uint32_t n_lights;
+    rthip_background background;
+} rthip_scene_desc;
+
+/* Camera basis of AbstractRaycaster::CreateScreenRay (Raytracer.cpp:102-121), computed once on
+ * the host: forward/right/up normalised, h2 = atan(fovY/2), w2 = h2*W/H. */
+typedef struct {
+    double position[3];
+    double forward[3];
+    double right[3];
+    double up[3];
+    double h2, w2;
+} rthip_camera;
+
+typedef struct {
+    uint32_t width, height;
+    uint32_t max_recursion;   /* Raytracer::MaxRecursion (Raytracer.h:104) */
+    int32_t aa_mode;          /* AbstractRaycaster::AAMode: 0 None, 1 SSAA (Raytracer.h:59-63) */
+    int32_t renderer;         /* RTHIP_RENDER_* */
+    /* screen partition for multi-GPU: this context renders the tiles t (row-major tile index,
+     * tiles of tile_w x tile_h pixels) with t % part_count == part_index.  part_count = 1 -> whole frame. */
+    uint32_t part_index, part_count;
+    uint32_t tile_w, tile_h;  /* 0 -> default 32 x 8 */
+} rthip_params;
+
+typedef struct {
+    uint64_t rays_primary, rays_shadow, rays_reflect;  /* Scene::CastRay-equivalent queries of the last render */
+    uint64_t pixels;                                   /* pixels rendered by this context */
+    float ms_total;                                    /* device time of the last render (HIP events) */
+    float ms_trace;                                    /* summed duration of the trace/shade kernels */
+    uint32_t launches_trace;                           /* number of trace/shade kernel launches */
+    uint32_t pad;
+    uint64_t kd_nodes_visited, kd_tris_tested, kd_leaves_visited; /* only with RTHIP_COUNTERS=1 builds/contexts */
+} rthip_stats;
+
+/* ---- lifecycle ---- */
+/* replaces: the std::async worker pool of AbstractRaycaster::Render (Raytracer.cpp:52-66) */
+int rthip_create(int device, rthip_ctx **out);
+int rthip_destroy(rthip_ctx *ctx);
+const char *rthip_last_error(void);
+
+/* replaces: the pointer-linked scene the reference walks per ray (Scene.cpp:168-237, 469-493);
+ * called once per frame after Scene::Compile (Raytracer.cpp:42) */
+int rthip_upload_scene(rthip_ctx *ctx, const rthip_scene_desc *scene);
+
+/* replaces: the per-pixel loop of AbstractRaycaster::DoRaytraceThread + ColorsToPixels
+ * (Raytracer.cpp:123-170) for the Raycast of re::Raytracer (Raytracer.cpp:187-315).
+ * out_pixels: host buffer, width*height uint32, index y*width+x, value = Color::GetHexValue
+ * (Common.cpp:275-282).  With part_count > 1 only this part's pixels are written.
+ * out_shape_id / out_tri_index (nullable, same indexing, int32): primary-hit shape ordinal
+ * (pre-order index into shapes[], -1 = miss) and mesh-relative triangle index (-1 = none). */
+int rthip_render(rthip_ctx *ctx, const rthip_camera *cam, const rthip_params *params,
+                 uint32_t *out_pixels, int32_t *out_shape_id, int32_t *out_tri_index);
+
+/* Same frame, output left in device memory (HBM): d_pixels is a device pointer to
+ * width*height uint32 (row-major); only this part's pixels are written.  Asynchronous on the
+ * context's stream unless `sync` is non-zero.  Used by bench.py and the multi-GPU gather. */
+int rthip_render_device(rthip_ctx *ctx, const rthip_camera *cam, const rthip_params *params,
+                        void *d_pixels, int sync);
+/* HIP stream the context launches on (hipStream_t as void*), so callers can order work after it */
+void *rthip_stream(rthip_ctx *ctx);
+int rthip_synchronize(rthip_ctx *ctx);
+
+/* replaces: RenderStatus::Percent polling and Interrupt() (Raytracer.cpp:91-99, 150-154);
+ * both callable from another thread while rthip_render runs */
+float rthip_progress(rthip_ctx *ctx);
+int rthip_interrupt(rthip_ctx *ctx);
+
+int rthip_get_stats(rthip_ctx *ctx, rthip_stats *out);
+
+/* Known-answer probes: run single device functions on n inputs (device parity tests of the
+ * S1/P1/P2/T2/T4, N0-N4, M1/M2, B1/B2 and R4 rows of SURVEY.md §8a against the oracle). */
+/* Scene::CastRay (Scene.cpp:163-237): o,d n*3 -> hit n, point/local/normal n*3, shape n, tri n */
+int rthip_probe_cast(rthip_ctx *ctx, uint32_t n, const double *o, const double *d, int32_t *hit,
+                     double *point, double *local, double *normal, int32_t *shape, int32_t *tri);
+/* Noise::Sample (noise/Noise.cpp:3-19) */
+int rthip_probe_noise(rthip_ctx *ctx, int32_t noise, uint32_t n, const double *p, double *out);
+/* Material::GetAbsorbedColor / GetAbsorptance (Material.cpp:21-29) */
+int rthip_probe_material(rthip_ctx *ctx, int32_t material, uint32_t n, const double *p,
+                         double *color, double *absorptance);
+/* Background::GetColor (Scene.cpp:111-151) */
+int rthip_probe_background(rthip_ctx *ctx, uint32_t n, const double *d, double *color);
+/* Raytracer::Raycast (Raytracer.cpp:312-315) on explicit rays -> unpacked colours n*3 */
+int rthip_probe_raycast(rthip_ctx *ctx, uint32_t max_recursion, uint32_t n, const double *o,
+                        const double *d, double *color);
+/* IEEE arithmetic self-check of the device (add/mul/div/sqrt/floor/fmodf/casts on n inputs):
+ * op 0 a+b, 1 a*b, 2 a/b, 3 sqrt(a), 4 floor(a), 5 (double)fmodf((float)a,(float)b),
+ * 6 (double)(float)a, 7 sin(a), 8 (double)(int)a, 9 fmax(a,b), 10 fmin(a,b) */
+int rthip_probe_arith(rthip_ctx *ctx, int32_t op, uint32_t n, const double *a, const double *b, double *out);
+
+const char *rthip_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,659 @@
+// rt_core.hpp — per-ray device functions of the Raycast hot path (gfx950), written once as
+// __host__ __device__ so tests can also compile them with g++ in a GPU-less container
+// (tests/hostcore).  The product only ever runs them inside the HIP kernels of rt_kernels.hip.
+//
+// Numerics contract: IEEE double, the reference's operation order, no FMA
+// contraction (-ffp-contract=off), float round-trips reproduced where the reference has them.
+// Each function cites the reference file:line whose arithmetic it reproduces; the structure
+// (flat pre-order shape table, ordered kd traversal with an explicit stack, postfix material
+// programs, iterative bounce) is this library's own.
+#pragma once
+#include <float.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "rthip.h"
+
+#if defined(__HIPCC__)
+#define RT_HD __host__ __device__ __forceinline__
+#define RT_HD_NOINLINE __host__ __device__ __noinline__
+#else
+#define RT_HD inline
+#define RT_HD_NOINLINE
+#endif
+
+namespace rtc {
+
+struct V3 {
+    double x, y, z;
+};
+struct Col {
+    double r, g, b;
+};
+
+// Device-resident flattened scene (pointers into HBM; see DESIGN.md "data layout").
+struct SceneView {
+    const rthip_shape *shapes;
+    uint32_t n_shapes;
+    const rthip_mesh *meshes;
+    const rthip_kdnode *kd_nodes;
+    const double *kd_bounds;
+    const uint32_t *kd_refs;
+    const rthip_tri *tris;
+    const double *tri_normals;
+    const rthip_matop *materials;
+    const rthip_noise *noises;
+    const uint8_t *perlin_tables;
+    const double *worley_points;
+    const rthip_light *lights;
+    uint32_t n_lights;
+    rthip_background bg;
+};
+
+// Traversal stack: `stride` lets the device interleave the lanes of a workgroup in LDS
+// (entry k of lane t lives at base[k*stride], base already offset by t).
+struct KdStack {
+    uint32_t *base;
+    uint32_t stride;
+    uint32_t cap;
+    uint32_t n;
+    RT_HD void clear() { n = 0; }
+    RT_HD bool empty() const { return n == 0; }
+    RT_HD void push(uint32_t v) {
+        if (n < cap) {
+            base[n * stride] = v;
+            n++;
+        }
+    }
+    RT_HD uint32_t pop() {
+        n--;
+        return base[n * stride];
+    }
+};
+
+struct KdCounters {
+    uint32_t nodes, leaves, tris;
+};
+
+// ----------------------------------------------------------------------------- math (C1)
+RT_HD V3 mk(double x, double y, double z) { return V3{x, y, z}; }
+RT_HD V3 add(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }    // Common.cpp:119
+RT_HD V3 sub(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }    // Common.cpp:123
+RT_HD V3 scale(V3 a, double t) { return mk(a.x * t, a.y * t, a.z * t); }    // Common.cpp:245
+RT_HD V3 divs(V3 a, double t) { return mk(a.x / t, a.y / t, a.z / t); }     // Common.cpp:250
+RT_HD double dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }  // Common.cpp:138
+RT_HD double sqlen(V3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }      // Common.cpp:37
+RT_HD double length(V3 a) { return sqrt(a.x * a.x + a.y * a.y + a.z * a.z); }  // Common.cpp:42
+RT_HD V3 normalized(V3 a) {                                                   // Common.cpp:47-58
+    double l = length(a);
+    if (l > 0) return mk(a.x / l, a.y / l, a.z / l);
+    return mk(0, 0, 0);
+}
+// Common.cpp:60-63: *this - normal * (normal ^ *this) * 2.0f
+RT_HD V3 reflect(V3 d, V3 n) { return sub(d, scale(scale(n, dot(n, d)), 2.0)); }
+RT_HD double comp(V3 a, uint32_t ax) { return ax == 0 ? a.x : (ax == 1 ? a.y : a.z); }
+
+// Common.h:22-25 Clamp(v, 0, 1) = std::max(0, std::min(1, v)) with the std:: tie/NaN behaviour
+RT_HD double clamp01(double v) {
+    double m = (v < 1.0) ? v : 1.0;
+    return (0.0 < m) ? m : 0.0;
+}
+RT_HD Col mkc(double r, double g, double b) { return Col{clamp01(r), clamp01(g), clamp01(b)}; }  // Common.cpp:260
+RT_HD Col c_add(Col a, Col b) { return mkc(a.r + b.r, a.g + b.g, a.b + b.b); }                 // Common.cpp:212
+RT_HD Col c_mul(Col a, Col b) { return mkc(a.r * b.r, a.g * b.g, a.b * b.b); }                 // Common.cpp:221
+RT_HD Col c_scale(Col a, double k) { return mkc(a.r * k, a.g * k, a.b * k); }                  // Common.cpp:230
+RT_HD Col c_mix(Col a, Col b, double t) {                                                       // Common.cpp:239-243
+    double _t = 1 - t;
+    return mkc(_t * a.r + t * b.r, _t * a.g + t * b.g, _t * a.b + t * b.b);
+}
+RT_HD Col c_from(const double *p) { return Col{p[0], p[1], p[2]}; }
+// Common.cpp:275-282 GetHexValue: truncating, R in the low byte
+RT_HD uint32_t c_pack(Col c) {
+    return 0xff000000u | ((uint32_t)(c.r * 255.0)) | (((uint32_t)(c.g * 255.0)) << 8) |
+           (((uint32_t)(c.b * 255.0)) << 16);
+}
+
+// Common.cpp:169-180 Matrix4 * Vector4 restricted to rows 0..2; the accumulator starts at 0 and
+// all four products are added in order (w = 1 for points, 0 for directions).
+RT_HD V3 xform(const double *m, V3 p, double w) {
+    V3 r;
+    r.x = (((0.0 + m[0] * p.x) + m[1] * p.y) + m[2] * p.z) + m[3] * w;
+    r.y = (((0.0 + m[4] * p.x) + m[5] * p.y) + m[6] * p.z) + m[7] * w;
+    r.z = (((0.0 + m[8] * p.x) + m[9] * p.y) + m[10] * p.z) + m[11] * w;
+    return r;
+}
+
+// ----------------------------------------------------------------------------- noise (N0-N4)
+RT_HD double lerp(double a, double b, double t) { return a * (1 - t) + b * t; }              // Common.h:27-30
+RT_HD double fade(double t) { return t * t * t * (t * (t * 6 - 15) + 10); }                 // Perlin.cpp:59-62
+
+// Perlin.cpp:57-83 SampleAtFrequency + Perlin.cpp:49-55 GetSeed.  frequency is a power of two,
+// so the reference's divisions by it are exact scalings (x / 2^k == x * 2^-k bit for bit).
+// The 24 chained table lookups of the reference collapse to 14 distinct ones.
+RT_HD double perlin_at_freq(const uint8_t *tab, V3 pos, double fq, double inv_fq) {
+    double fx = floor(pos.x * inv_fq) * fq, fy = floor(pos.y * inv_fq) * fq, fz = floor(pos.z * inv_fq) * fq;
+    uint32_t x0 = (uint32_t)fx, y0 = (uint32_t)fy, z0 = (uint32_t)fz;
+    uint32_t x1 = (uint32_t)(fx + fq), y1 = (uint32_t)(fy + fq), z1 = (uint32_t)(fz + fq);
+    uint32_t ix0 = tab[x0 & 255u], ix1 = tab[x1 & 255u];
+    uint32_t i00 = tab[(ix0 + y0) & 255u], i10 = tab[(ix1 + y0) & 255u];
+    uint32_t i01 = tab[(ix0 + y1) & 255u], i11 = tab[(ix1 + y1) & 255u];
+    const double k = 1.0 / 256.0;
+    double a = tab[(i00 + z0) & 255u] * k, b = tab[(i10 + z0) & 255u] * k;
+    double c = tab[(i01 + z0) & 255u] * k, d = tab[(i11 + z0) & 255u] * k;
+    double e = tab[(i00 + z1) & 255u] * k, f = tab[(i10 + z1) & 255u] * k;
+    double g = tab[(i01 + z1) & 255u] * k, h = tab[(i11 + z1) & 255u] * k;
+    double u = fade((pos.x - fx) * inv_fq), v = fade((pos.y - fy) * inv_fq), w = fade((pos.z - fz) * inv_fq);
+    return lerp(lerp(lerp(a, b, u), lerp(c, d, u), v), lerp(lerp(e, f, u), lerp(g, h, u), v), w);
+}
+// Perlin.cpp:25-47 SampleNormalized
+RT_HD double perlin_normalized(const uint8_t *tab, uint32_t octaves, double persistance, V3 p) {
+    double amplitude = 1.0, acc = 0.0, result = 0.0;
+    double fq = 256.0, inv_fq = 1.0 / 256.0;
+    V3 rpos = scale(p, 256.0);
+    for (uint32_t i = 0; i < octaves; i++) {
+        result += amplitude * perlin_at_freq(tab, rpos, fq, inv_fq);
+        fq *= 0.5;
+        inv_fq *= 2.0;
+        acc += amplitude;
+        amplitude *= persistance;
+    }
+    return result / acc;
+}
+// Worley.cpp:29-57 SampleNormalized, :59-84 helpers
+RT_HD double worley_normalized(const double *pts, int div, double step, V3 p) {
+    double maxDistance = step * (double)sqrtf(3.0f);
+    int x = (int)(p.x * div), y = (int)(p.y * div), z = (int)(p.z * div);
+    double distance = (double)FLT_MAX;
+    for (int dx = -1; dx <= 1; dx++)
+        for (int dy = -1; dy <= 1; dy++)
+            for (int dz = -1; dz <= 1; dz++) {
+                int cx = x + dx, cy = y + dy, cz = z + dz;
+                int ox = cx < 0 ? -1 : (cx >= div ? 1 : 0);
+                int oy = cy < 0 ? -1 : (cy >= div ? 1 : 0);
+                int oz = cz < 0 ? -1 : (cz >= div ? 1 : 0);
+                int wx = ((cx % div) + div) % div, wy = ((cy % div) + div) % div, wz = ((cz % div) + div) % div;
+                const double *q = pts + 3 * (size_t)(wz * div * div + wy * div + wx);
+                V3 fp = mk(q[0] + (double)ox, q[1] + (double)oy, q[2] + (double)oz);
+                double d = sqlen(sub(fp, p));
+                if (d < distance) distance = d;
+            }
+    return distance / maxDistance * 10.0;
+}
+// Noise.cpp:3-19: fmodf rounds point and domain to float; its float result is divided by the double domain
+RT_HD double noise_wrap(double x, double domain) {
+    x = (double)fmodf((float)x, (float)domain) / domain;
+    return x < 0 ? 1.0 + x : x;
+}
+RT_HD double noise_sample(const SceneView &sv, int32_t ni, V3 p) {
+    const rthip_noise &n = sv.noises[ni];
+    V3 q = mk(noise_wrap(p.x, n.domain), noise_wrap(p.y, n.domain), noise_wrap(p.z, n.domain));
+    switch (n.type) {
+    case RTHIP_NOISE_CHECKER: {  // CheckerBoard.cpp:3-16
+        int t0 = q.x <= 0.5, t2 = q.z <= 0.5;
+        return (double)(t2 ^ t0);
+    }
+    case RTHIP_NOISE_PERLIN:
+        return perlin_normalized(sv.perlin_tables + 256 * (size_t)n.table, n.octaves, n.persistance, q);
+    case RTHIP_NOISE_WORLEY:
+        return worley_normalized(sv.worley_points + 3 * (size_t)n.points_base, n.divisions, n.step, q);
+    default: {  // Marble.cpp:11-15
+        double f = perlin_normalized(sv.perlin_tables + 256 * (size_t)n.table, n.octaves, n.persistance, q) * n.turbolence;
+        return fabs(sin(f * n.frequency * (double)3.141592f));
+    }
+    }
+}
+
+// ----------------------------------------------------------------------------- materials (M1, M2)
+// Evaluates the postfix program ending at op `root`: Lerp<Color> = a*(1-t) (+) b*t with clamping
+// Color ops, Lerp<real> unclamped (Material.cpp:21-29).  Noise is sampled once per INTERP node
+// (the reference re-samples it per query; Sample is a pure function of the point).
+RT_HD void material_eval(const SceneView &sv, int32_t root, V3 p, Col &color, double &absorptance) {
+    const rthip_matop &r = sv.materials[root];
+    if (r.op == RTHIP_MAT_UNIFORM) {
+        color = c_from(r.color);
+        absorptance = r.absorptance;
+        return;
+    }
+    if (root - r.first_op == 2) {  // INTERP of two UNIFORMs: no stack needed
+        const rthip_matop &a = sv.materials[root - 2], &b = sv.materials[root - 1];
+        double t = noise_sample(sv, r.noise, p);
+        color = c_add(c_scale(c_from(a.color), 1 - t), c_scale(c_from(b.color), t));
+        absorptance = lerp(a.absorptance, b.absorptance, t);
+        return;
+    }
+    Col cs[RTHIP_MAX_MAT_STACK];
+    double as[RTHIP_MAX_MAT_STACK];
+    int sp = 0;
+    for (int32_t i = r.first_op; i <= root; i++) {
+        const rthip_matop &m = sv.materials[i];
+        if (m.op == RTHIP_MAT_UNIFORM) {
+            if (sp < RTHIP_MAX_MAT_STACK) {
+                cs[sp] = c_from(m.color);
+                as[sp] = m.absorptance;
+                sp++;
+            }
+        } else if (sp >= 2) {
+            double t = noise_sample(sv, m.noise, p);
+            Col a = cs[sp - 2], b = cs[sp - 1];
+            double aa = as[sp - 2], ab = as[sp - 1];
+            sp--;
+            cs[sp - 1] = c_add(c_scale(a, 1 - t), c_scale(b, t));
+            as[sp - 1] = lerp(aa, ab, t);
+        }
+    }
+    color = cs[0];
+    absorptance = as[0];
+}
+
+// ----------------------------------------------------------------------------- background (B1, B2)
+// Scene.cpp:111-151 SkyBox::GetColor; Scene.h:43-49 ColorBackground
+RT_HD Col background_color(const SceneView &sv, V3 direction) {
+    const rthip_background &bg = sv.bg;
+    if (bg.type == RTHIP_BG_NONE) return Col{0, 0, 0};  // Raytracer.cpp:296-299
+    if (bg.type == RTHIP_BG_COLOR) return c_from(bg.color0);
+    const float thresold = 0.98f;
+    const float border = (1.0f - thresold) / 2.0f;
+    const float thresoldPlusBorder = thresold + border;
+    V3 q = divs(add(direction, mk(1, 1, 1)), 2.0);
+    V3 w = mk(noise_wrap(q.x, 1.0), noise_wrap(q.y, 1.0), noise_wrap(q.z, 1.0));
+    double sample = perlin_normalized(sv.perlin_tables + 256 * (size_t)bg.table, 8, 0.5, w);
+    Col color = c_mix(c_from(bg.color0), c_from(bg.color1), sample);
+    if (bg.sun_light >= 0 && sv.lights[bg.sun_light].type == RTHIP_LIGHT_DIRECTIONAL) {
+        const rthip_light &sun = sv.lights[bg.sun_light];
+        float f = fmaxf(0.0f, (float)dot(direction, mk(sun.direction[0], sun.direction[1], sun.direction[2])));
+        if (f < thresold) return color;
+        if (f < thresoldPlusBorder) {
+            // powf(x, 2.0f) of the reference: glibc's powf is correctly rounded here and equals the
+            // float product x*x (checked exhaustively over [0,1], tests/test_oracle_golden.py)
+            float x = (f - thresold) / border;
+            f = x * x;
+            return c_mix(color, c_from(sun.color), (double)f);
+        }
+        return c_from(sun.color);
+    }
+    return color;
+}
+
+// ----------------------------------------------------------------------------- primitives (P1, P2, T2)
+struct LocalHit {
+    bool hit;
+    V3 point;
+    V3 normal;
+    int32_t tri;
+};
+
+// Scene.cpp:294-330 Sphere::Intersect (unit sphere at the local origin)
+RT_HD bool sphere_intersect(V3 o, V3 d, V3 &point) {
+    double projection = dot(sub(mk(0, 0, 0), o), d);
+    double squaredDistance = dot(o, o) - projection * projection;
+    if (squaredDistance > 1.0) return false;
+    double offset = sqrt(1.0 - squaredDistance);
+    double t1 = projection - offset, t2 = projection + offset;
+    if (t1 < 0 && t2 < 0) return false;
+    point = add(o, scale(d, (t1 >= 0.0 ? t1 : t2)));
+    return true;
+}
+// Scene.cpp:332-362 Plane::Intersect (one-sided, through the local origin, un-normalised Normal)
+RT_HD bool plane_intersect(V3 n, V3 o, V3 d, V3 &point) {
+    double distance = dot(o, n);
+    if (distance < 0) return false;
+    double cosine = dot(n, d);
+    if (cosine >= 0) return false;
+    point = add(o, scale(d, distance / -cosine));
+    return true;
+}
+
+struct TriBest {
+    double d;      // |O - P|^2 exactly as Scene.cpp:477
+    V3 point;
+    double u, v, w;
+    uint32_t tri;  // mesh-relative triangle index
+    uint32_t ref;  // position in the pre-order leaf-reference array (tie order)
+    bool hit;
+};
+
+// Scene.cpp:421-467 IntersectTriangle + :495-507 Baricentric: plane projection, back-face /
+// behind-plane cull, inclusive barycentric test.  Updates `best` with the strict '<' of Scene.cpp:479
+// (exact ties keep the candidate that comes first in the reference's pre-order walk).
+RT_HD void tri_test(const rthip_tri &t, V3 o, V3 d, uint32_t tri, uint32_t ref, TriBest &best) {
+    V3 v0 = mk(t.v0[0], t.v0[1], t.v0[2]);
+    V3 nf = mk(t.face_normal[0], t.face_normal[1], t.face_normal[2]);
+    V3 l = sub(o, v0);
+    double distance = dot(l, nf);
+    if (distance < 0) return;
+    double cosine = dot(d, nf);
+    if (cosine >= 0) return;
+    V3 projection = add(o, scale(d, distance / -cosine));
+    V3 v2 = sub(projection, v0);
+    double d20 = dot(v2, mk(t.e0[0], t.e0[1], t.e0[2]));
+    double d21 = dot(v2, mk(t.e1[0], t.e1[1], t.e1[2]));
+    double v = (t.d11 * d20 - t.d01 * d21) * t.inv_den;
+    double w = (t.d00 * d21 - t.d01 * d20) * t.inv_den;
+    double u = 1.0 - v - w;
+    if (u >= 0 && v >= 0 && w >= 0) {
+        double dd = sqlen(sub(o, projection));
+        if (dd < best.d || (best.hit && dd == best.d && ref < best.ref)) {
+            best.d = dd;
+            best.point = projection;
+            best.u = u;
+            best.v = v;
+            best.w = w;
+            best.tri = tri;
+            best.ref = ref;
+            best.hit = true;
+        }
+    }
+}
+
+// Common.cpp:345-363 BoundingBox::Intersect on precomputed plane parameters
+// t[0..5] = (Min.x-O.x)/D.x, (Max.x-O.x)/D.x, (Min.y..)/D.y, (Max.y..)/D.y, (Min.z..)/D.z, (Max.z..)/D.z
+RT_HD bool slab_hit(const double *t, double &t7) {
+    t7 = fmax(fmax(fmin(t[0], t[1]), fmin(t[2], t[3])), fmin(t[4], t[5]));
+    double t8 = fmin(fmin(fmax(t[0], t[1]), fmax(t[2], t[3])), fmax(t[4], t[5]));
+    double t9 = (t8 < 0 || t7 > t8) ? -1.0 : t7;
+    return t9 != -1.0;
+}
+RT_HD void slab_params(const double *b, V3 o, V3 d, double *t) {
+    t[0] = (b[0] - o.x) / d.x;
+    t[1] = (b[3] - o.x) / d.x;
+    t[2] = (b[1] - o.y) / d.y;
+    t[3] = (b[4] - o.y) / d.y;
+    t[4] = (b[2] - o.z) / d.z;
+    t[5] = (b[5] - o.z) / d.z;
+}
+// A subtree whose box the ray enters at parameter t7 (|D| = 1) cannot hold a hit point closer than
+// t7; it is skipped once the best squared distance is safely below t7^2 (1e-9 relative slack covers
+// the rounding of both sides).  Skipping never changes the argmin the reference computes.
+RT_HD bool kd_prunable(double t7, const TriBest &best) {
+    return best.hit && t7 > 0.0 && t7 * t7 * (1.0 - 1e-9) > best.d;
+}
+
+// T4: Mesh::Intersect / IntersectInternal (Scene.cpp:372-378, 469-493).  The reference visits every
+// node whose box (and all ancestor boxes) pass BoundingBox::Intersect and keeps the strictly
+// closest triangle hit.  This traversal applies the same box test with the same arithmetic to every
+// node it visits, but descends near-child first and skips subtrees that cannot beat the current
+// best, so it reaches the same argmin with a fraction of the node/triangle tests.  A child's box
+// differs from its parent's in one plane (BoundingBox::Split, Common.cpp:313-338), so descending
+// costs one division; the six plane parameters are recomputed from the stored bounds on a pop.
+RT_HD void mesh_closest(const SceneView &sv, const rthip_mesh &m, V3 o, V3 d, KdStack &st, TriBest &best,
+                        KdCounters *cnt) {
+    best.hit = false;
+    best.d = DBL_MAX;
+    best.tri = 0xffffffffu;
+    best.ref = 0xffffffffu;
+    if (m.node_count == 0) return;
+    const rthip_kdnode *nodes = sv.kd_nodes + m.node_base;
+    const double *bounds = sv.kd_bounds + 6 * (size_t)m.node_base;
+    const uint32_t *refs = sv.kd_refs + m.ref_base;
+    const rthip_tri *tris = sv.tris + m.tri_base;
+    double t[6], t7;
+    slab_params(bounds, o, d, t);
+    if (cnt) cnt->nodes++;
+    if (!slab_hit(t, t7)) return;
+    st.clear();
+    uint32_t cur = 0;
+    for (;;) {
+        rthip_kdnode nd = nodes[cur];
+        bool descend = false;
+        if (nd.info & RTHIP_KD_LEAF) {
+            uint32_t count = nd.info >> RTHIP_KD_COUNT_SHIFT;
+            if (cnt) {
+                cnt->leaves++;
+                cnt->tris += count;
+            }
+            for (uint32_t i = 0; i < count; i++) {
+                uint32_t ti = refs[nd.link + i];
+                tri_test(tris[ti], o, d, ti, nd.link + i, best);
+            }
+        } else {
+            uint32_t ax = nd.info & RTHIP_KD_AXIS_MASK;
+            double ts = (nd.split - comp(o, ax)) / comp(d, ax);
+            // left child: Max[ax] = split; right child: Min[ax] = split
+            // every index below is a compile-time constant after unrolling: runtime-indexed
+            // register arrays would be demoted to scratch memory on gfx950
+            double tl[6], tr[6], t7l = 0, t7r = 0;
+            const int ihi = (int)(2 * ax + 1), ilo = (int)(2 * ax);
+#pragma unroll
+            for (int k = 0; k < 6; k++) {
+                tl[k] = (k == ihi) ? ts : t[k];
+                tr[k] = (k == ilo) ? ts : t[k];
+            }
+            bool hl = (nd.info & RTHIP_KD_HAS_LEFT) && slab_hit(tl, t7l) && !kd_prunable(t7l, best);
+            bool hr = (nd.info & RTHIP_KD_HAS_RIGHT) && slab_hit(tr, t7r) && !kd_prunable(t7r, best);
+            if (cnt) cnt->nodes += ((nd.info & RTHIP_KD_HAS_LEFT) ? 1 : 0) + ((nd.info & RTHIP_KD_HAS_RIGHT) ? 1 : 0);
+            if (hl && hr) {
+                bool left_first = t7l <= t7r;
+                st.push(left_first ? nd.link : cur + 1);
+                cur = left_first ? cur + 1 : nd.link;
+#pragma unroll
+                for (int k = 0; k < 6; k++) t[k] = left_first ? tl[k] : tr[k];
+                descend = true;
+            } else if (hl) {
+                cur = cur + 1;
+#pragma unroll
+                for (int k = 0; k < 6; k++) t[k] = tl[k];
+                descend = true;
+            } else if (hr) {
+                cur = nd.link;
+#pragma unroll
+                for (int k = 0; k < 6; k++) t[k] = tr[k];
+                descend = true;
+            }
+        }
+        if (descend) continue;
+        // pop the next pending subtree that can still matter
+        bool found = false;
+        while (!st.empty()) {
+            cur = st.pop();
+            slab_params(bounds + 6 * (size_t)cur, o, d, t);
+            if (slab_hit(t, t7) && !kd_prunable(t7, best)) {
+                found = true;
+                break;
+            }
+        }
+        if (!found) break;
+    }
+}
+
+// ----------------------------------------------------------------------------- scene query (S1)
+struct Hit {
+    int32_t shape;  // pre-order ordinal into sv.shapes, -1 = miss
+    int32_t tri;    // mesh-relative triangle index or -1
+    V3 point, local, normal;
+};
+
+// Scene::CastRay / CastRayRecursive (Scene.cpp:163-237) over the flat pre-order shape table:
+// per shape world->local ray, Intersect, local->world point, accept iff d^2 >= DBL_EPSILON
+// (Scene.cpp:200), keep the strictly smallest d^2 (earlier node wins ties, Scene.cpp:225).
+// any_hit: stop at the first accepted shape (CastShadowRay only consumes .Hit, Raytracer.cpp:305-310).
+RT_HD Hit cast_ray(const SceneView &sv, V3 o, V3 d, KdStack &st, bool any_hit, KdCounters *cnt) {
+    Hit best;
+    best.shape = -1;
+    best.tri = -1;
+    best.point = best.local = best.normal = mk(0, 0, 0);
+    double hitDistance = DBL_MAX;
+    V3 best_local_normal = mk(0, 0, 0);
+    for (uint32_t s = 0; s < sv.n_shapes; s++) {
+        const rthip_shape &sh = sv.shapes[s];
+        V3 lo = xform(sh.inv, o, 1.0);
+        V3 ld = normalized(xform(sh.inv, d, 0.0));
+        V3 p = mk(0, 0, 0), ln = mk(0, 0, 0);
+        int32_t tri = -1;
+        bool hit;
+        TriBest tb;
+        if (sh.type == RTHIP_SHAPE_SPHERE) {
+            hit = sphere_intersect(lo, ld, p);
+        } else if (sh.type == RTHIP_SHAPE_PLANE) {
+            hit = plane_intersect(mk(sh.plane_n[0], sh.plane_n[1], sh.plane_n[2]), lo, ld, p);
+        } else {
+            mesh_closest(sv, sv.meshes[sh.mesh], lo, ld, st, tb, cnt);
+            hit = tb.hit;
+            p = tb.point;
+            tri = (int32_t)tb.tri;
+        }
+        if (!hit) continue;
+        V3 worldPoint = xform(sh.fwd, p, 1.0);
+        double distance = sqlen(sub(o, worldPoint));
+        if (!(distance >= DBL_EPSILON)) continue;
+        if (!(distance < hitDistance)) continue;
+        hitDistance = distance;
+        best.shape = (int32_t)s;
+        best.tri = tri;
+        best.point = worldPoint;
+        best.local = p;
+        if (any_hit) return best;
+        if (sh.type == RTHIP_SHAPE_SPHERE) {
+            ln = normalized(p);  // Scene.cpp:327
+        } else if (sh.type == RTHIP_SHAPE_PLANE) {
+            ln = mk(sh.plane_n[0], sh.plane_n[1], sh.plane_n[2]);  // Scene.cpp:359
+        } else {
+            const rthip_mesh &m = sv.meshes[sh.mesh];
+            if (m.normal_mode == 0) {
+                const rthip_tri &t = sv.tris[m.tri_base + tb.tri];
+                ln = mk(t.face_normal[0], t.face_normal[1], t.face_normal[2]);  // Scene.cpp:458
+            } else {  // Scene.cpp:462
+                const double *n = sv.tri_normals + 9 * (size_t)(m.tri_base + tb.tri);
+                ln = normalized(add(add(scale(mk(n[0], n[1], n[2]), tb.u), scale(mk(n[3], n[4], n[5]), tb.v)),
+                                    scale(mk(n[6], n[7], n[8]), tb.w)));
+            }
+        }
+        best_local_normal = ln;
+    }
+    if (best.shape >= 0 && !any_hit)
+        best.normal = normalized(xform(sv.shapes[best.shape].nrm, best_local_normal, 0.0));  // Scene.cpp:208
+    return best;
+}
+
+// ----------------------------------------------------------------------------- shading (R4-R6)
+struct Bounce {
+    Col color;      // miss: background; hit: directLighting (Raytracer.cpp:192, 269-270)
+    double refl;    // reflectance applied to the child's colour (Raytracer.cpp:283)
+    bool spawn;     // a reflected ray follows (Raytracer.cpp:276)
+    V3 child_o, child_d;
+    int32_t shape, tri;
+    uint32_t shadow_rays;
+};
+
+// One level of Raytracer::RecursiveRaytrace (Raytracer.cpp:187-303) without the recursive call:
+// closest hit, per-light shadow query + Lambert term, and the reflected ray if any.
+RT_HD void bounce(const SceneView &sv, V3 ro, V3 rd, bool may_reflect, KdStack &st, Bounce &out, KdCounters *cnt) {
+    Hit h = cast_ray(sv, ro, rd, st, false, cnt);
+    out.shape = h.shape;
+    out.tri = h.tri;
+    out.spawn = false;
+    out.refl = 0.0;
+    out.shadow_rays = 0;
+    if (h.shape < 0) {
+        out.color = background_color(sv, rd);
+        return;
+    }
+    Col albedo;
+    double absorptance;
+    material_eval(sv, sv.shapes[h.shape].material, h.local, albedo, absorptance);
+    double reflectance = 1.0 - absorptance;  // Material.cpp:9-12
+    Col direct = Col{0, 0, 0};
+    if (absorptance > 0) {
+        for (uint32_t li = 0; li < sv.n_lights; li++) {
+            const rthip_light &light = sv.lights[li];
+            if (!light.enabled) continue;
+            V3 ldir = mk(light.direction[0], light.direction[1], light.direction[2]);
+            V3 lpos = mk(light.position[0], light.position[1], light.position[2]);
+            bool shadowed = false;
+            if (light.type == RTHIP_LIGHT_DIRECTIONAL) {
+                out.shadow_rays++;
+                shadowed = cast_ray(sv, h.point, ldir, st, true, cnt).shape >= 0;
+            } else if (light.type == RTHIP_LIGHT_POINT) {
+                out.shadow_rays++;
+                shadowed = cast_ray(sv, h.point, normalized(sub(lpos, h.point)), st, true, cnt).shape >= 0;
+            }
+            if (shadowed) continue;
+            double diffuseFactor = 0.0;
+            if (light.type == RTHIP_LIGHT_DIRECTIONAL) {
+                diffuseFactor = (double)fmaxf(0.0f, (float)dot(h.normal, ldir));  // Raytracer.cpp:252
+            } else if (light.type == RTHIP_LIGHT_POINT) {                        // Raytracer.cpp:255-259
+                V3 lightVector = sub(lpos, h.point);
+                V3 direction = normalized(lightVector);
+                double distance = length(lightVector);
+                double attenuation = 1.0 - ((distance * distance) / (light.attenuation * light.attenuation));
+                diffuseFactor = (double)fmaxf(0.0f, (float)dot(direction, h.normal)) * attenuation;
+            } else {
+                diffuseFactor = 1.0;  // Raytracer.cpp:263
+            }
+            Col term = c_scale(c_scale(c_mul(c_from(light.color), albedo), diffuseFactor), absorptance);
+            direct = c_add(direct, term);
+        }
+    }
+    out.color = direct;
+    if (reflectance > 0 && may_reflect) {
+        out.spawn = true;
+        out.refl = reflectance;
+        out.child_o = h.point;
+        out.child_d = reflect(rd, h.normal);
+    }
+}
+
+// Fold of one level: directLighting + (child * reflectance) with clamping Color ops (Raytracer.cpp:283, 286)
+RT_HD Col fold(Col direct, Col child, double refl) { return c_add(direct, c_scale(child, refl)); }
+
+// Whole Raytracer::Raycast for one ray, iteratively (used by probes; the frame kernels run the
+// same bounce() level by level over compacted ray queues).
+RT_HD Col raycast(const SceneView &sv, V3 o, V3 d, uint32_t max_recursion, KdStack &st, uint32_t *n_rays) {
+    Col direct[RTHIP_MAX_RECURSION + 1];
+    double refl[RTHIP_MAX_RECURSION + 1];
+    uint32_t level = 0, rays = 0;
+    Col c;
+    for (;;) {
+        Bounce b;
+        bounce(sv, o, d, level < max_recursion, st, b, nullptr);
+        rays += 1 + b.shadow_rays;
+        if (!b.spawn) {
+            // hit without reflection returns directLighting + Black (identity on clamped colours)
+            c = b.shape < 0 ? b.color : c_add(b.color, Col{0, 0, 0});
+            break;
+        }
+        direct[level] = b.color;
+        refl[level] = b.refl;
+        o = b.child_o;
+        d = b.child_d;
+        level++;
+    }
+    while (level > 0) {
+        level--;
+        c = fold(direct[level], c, refl[level]);
+    }
+    if (n_rays) *n_rays = rays;
+    return c;
+}
+
+// DebugRaycaster::Raycast (Raytracer.cpp:317-351); mode 0 Normal, 1 Color
+RT_HD Col debug_raycast(const SceneView &sv, V3 o, V3 d, int mode, KdStack &st, int32_t *shape, int32_t *tri) {
+    Hit h = cast_ray(sv, o, d, st, false, nullptr);
+    if (shape) *shape = h.shape;
+    if (tri) *tri = h.tri;
+    if (mode == 0) {
+        if (h.shape >= 0) return mkc((h.normal.x + 1) / 2, (h.normal.y + 1) / 2, 1 - (h.normal.z + 1) / 2);
+        return Col{0, 0, 0};
+    }
+    if (h.shape >= 0) {
+        Col albedo;
+        double a;
+        material_eval(sv, sv.shapes[h.shape].material, h.local, albedo, a);
+        return albedo;
+    }
+    return background_color(sv, d);
+}
+
+// ----------------------------------------------------------------------------- ray generation (R1)
+// AbstractRaycaster::CreateScreenRay (Raytracer.cpp:102-121) with the camera basis, h2 and w2
+// hoisted to the host (rthip_camera); x, y are the real pixel coordinates (integers, or +-0.5 for SSAA).
+RT_HD void screen_ray(const rthip_camera &cam, uint32_t W, uint32_t H, double x, double y, V3 &o, V3 &d) {
+    double xFactor = (x / (double)W) * 2.0 - 1.0;
+    double yFactor = 1.0 - (y / (double)H) * 2.0;
+    V3 fw = mk(cam.forward[0], cam.forward[1], cam.forward[2]);
+    V3 rt = mk(cam.right[0], cam.right[1], cam.right[2]);
+    V3 up = mk(cam.up[0], cam.up[1], cam.up[2]);
+    o = mk(cam.position[0], cam.position[1], cam.position[2]);
+    d = normalized(add(add(fw, scale(scale(rt, xFactor), cam.w2)), scale(scale(up, yFactor), cam.h2)));
+}
+
+}  // namespace rtc

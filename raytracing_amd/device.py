@@ -1,0 +1,180 @@
+"""ctypes binding of the C-ABI in include/rthip.h (raytracing_amd/lib/librthip.so).
+
+Fails loudly when the HIP library is missing or a call fails: there is no CPU path."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+RTHIP_SO = os.path.join(_HERE, "lib", "librthip.so")
+
+c_dp = C.POINTER(C.c_double)
+c_i32p = C.POINTER(C.c_int32)
+c_u32p = C.POINTER(C.c_uint32)
+
+# every symbol include/rthip.h declares
+SYMBOLS = ["rthip_create", "rthip_destroy", "rthip_last_error", "rthip_upload_scene", "rthip_render",
+           "rthip_render_device", "rthip_stream", "rthip_synchronize", "rthip_progress", "rthip_interrupt",
+           "rthip_get_stats", "rthip_probe_cast", "rthip_probe_noise", "rthip_probe_material",
+           "rthip_probe_background", "rthip_probe_raycast", "rthip_probe_arith", "rthip_version"]
+
+
+class Camera(C.Structure):
+    _fields_ = [("position", C.c_double * 3), ("forward", C.c_double * 3), ("right", C.c_double * 3),
+                ("up", C.c_double * 3), ("h2", C.c_double), ("w2", C.c_double)]
+
+
+class Params(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("max_recursion", C.c_uint32),
+                ("aa_mode", C.c_int32), ("renderer", C.c_int32), ("part_index", C.c_uint32),
+                ("part_count", C.c_uint32), ("tile_w", C.c_uint32), ("tile_h", C.c_uint32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("rays_primary", C.c_uint64), ("rays_shadow", C.c_uint64), ("rays_reflect", C.c_uint64),
+                ("pixels", C.c_uint64), ("ms_total", C.c_float), ("ms_trace", C.c_float),
+                ("launches_trace", C.c_uint32), ("pad", C.c_uint32), ("kd_nodes_visited", C.c_uint64),
+                ("kd_tris_tested", C.c_uint64), ("kd_leaves_visited", C.c_uint64)]
+
+
+class RthipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"rthip error {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def lib():
+    """Loads librthip.so (built by raytracing_amd/csrc/Makefile or __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(RTHIP_SO):
+        raise RuntimeError(f"{RTHIP_SO} is missing: build it first (python -c 'import __graft_entry__ as g; g.build()'); "
+                           "the Raycast path has no CPU fallback")
+    L = C.CDLL(RTHIP_SO)
+    vp = C.c_void_p
+    L.rthip_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.rthip_destroy.argtypes = [vp]
+    L.rthip_last_error.restype = C.c_char_p
+    L.rthip_version.restype = C.c_char_p
+    L.rthip_upload_scene.argtypes = [vp, vp]
+    L.rthip_render.argtypes = [vp, C.POINTER(Camera), C.POINTER(Params), c_u32p, c_i32p, c_i32p]
+    L.rthip_render_device.argtypes = [vp, C.POINTER(Camera), C.POINTER(Params), vp, C.c_int]
+    L.rthip_stream.argtypes = [vp]
+    L.rthip_stream.restype = vp
+    L.rthip_synchronize.argtypes = [vp]
+    L.rthip_progress.argtypes = [vp]
+    L.rthip_progress.restype = C.c_float
+    L.rthip_interrupt.argtypes = [vp]
+    L.rthip_get_stats.argtypes = [vp, C.POINTER(Stats)]
+    L.rthip_probe_cast.argtypes = [vp, C.c_uint32, c_dp, c_dp, c_i32p, c_dp, c_dp, c_dp, c_i32p, c_i32p]
+    L.rthip_probe_noise.argtypes = [vp, C.c_int32, C.c_uint32, c_dp, c_dp]
+    L.rthip_probe_material.argtypes = [vp, C.c_int32, C.c_uint32, c_dp, c_dp, c_dp]
+    L.rthip_probe_background.argtypes = [vp, C.c_uint32, c_dp, c_dp]
+    L.rthip_probe_raycast.argtypes = [vp, C.c_uint32, C.c_uint32, c_dp, c_dp, c_dp]
+    L.rthip_probe_arith.argtypes = [vp, C.c_int32, C.c_uint32, c_dp, c_dp, c_dp]
+    _lib = L
+    return L
+
+
+def _dp(a):
+    return None if a is None else a.ctypes.data_as(c_dp)
+
+
+def make_params(width, height, max_recursion=3, aa=0, renderer=0, part_index=0, part_count=1, tile_w=0, tile_h=0):
+    return Params(width, height, max_recursion, aa, renderer, part_index, part_count, tile_w, tile_h)
+
+
+class Context:
+    """One rthip_ctx (one per process per GPU)."""
+
+    def __init__(self, device=0):
+        self.L = lib()
+        h = C.c_void_p()
+        self._check(self.L.rthip_create(device, C.byref(h)))
+        self.h = h
+
+    def _check(self, rc):
+        if rc != 0:
+            raise RthipError(rc, self.L.rthip_last_error().decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.rthip_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def upload(self, desc_ptr):
+        """desc_ptr: `const rthip_scene_desc*` (e.g. from host.HostScene.flatten())."""
+        self._check(self.L.rthip_upload_scene(self.h, desc_ptr))
+
+    def render(self, cam, params, ids=False, out=None):
+        n = params.width * params.height
+        px = out if out is not None else np.zeros((params.height, params.width), np.uint32)
+        sh = np.full((params.height, params.width), -1, np.int32) if ids else None
+        tr = np.full((params.height, params.width), -1, np.int32) if ids else None
+        self._check(self.L.rthip_render(self.h, C.byref(cam), C.byref(params), px.ctypes.data_as(c_u32p),
+                                        sh.ctypes.data_as(c_i32p) if ids else None,
+                                        tr.ctypes.data_as(c_i32p) if ids else None))
+        assert px.size == n
+        return {"pixels": px, "shape": sh, "tri": tr}
+
+    def render_device(self, cam, params, d_pixels_ptr, sync=False):
+        self._check(self.L.rthip_render_device(self.h, C.byref(cam), C.byref(params), C.c_void_p(d_pixels_ptr), int(sync)))
+
+    def synchronize(self):
+        self._check(self.L.rthip_synchronize(self.h))
+
+    def stream(self):
+        return self.L.rthip_stream(self.h)
+
+    def stats(self):
+        s = Stats()
+        self._check(self.L.rthip_get_stats(self.h, C.byref(s)))
+        return s
+
+    def probe_arith(self, op, a, b=None):
+        a = np.ascontiguousarray(a, np.float64)
+        b = None if b is None else np.ascontiguousarray(b, np.float64)
+        out = np.zeros_like(a)
+        self._check(self.L.rthip_probe_arith(self.h, op, a.size, _dp(a), _dp(b), _dp(out)))
+        return out
+
+    def probe_cast(self, o, d):
+        o = np.ascontiguousarray(o, np.float64).reshape(-1, 3); d = np.ascontiguousarray(d, np.float64).reshape(-1, 3)
+        n = len(o)
+        hit = np.zeros(n, np.int32); sh = np.zeros(n, np.int32); tr = np.zeros(n, np.int32)
+        pt = np.zeros((n, 3)); lp = np.zeros((n, 3)); nr = np.zeros((n, 3))
+        self._check(self.L.rthip_probe_cast(self.h, n, _dp(o), _dp(d), hit.ctypes.data_as(c_i32p), _dp(pt), _dp(lp), _dp(nr),
+                                            sh.ctypes.data_as(c_i32p), tr.ctypes.data_as(c_i32p)))
+        return {"hit": hit, "point": pt, "local": lp, "normal": nr, "shape": sh, "tri": tr}
+
+    def probe_noise(self, noise, p):
+        p = np.ascontiguousarray(p, np.float64).reshape(-1, 3); out = np.zeros(len(p))
+        self._check(self.L.rthip_probe_noise(self.h, noise, len(p), _dp(p), _dp(out)))
+        return out
+
+    def probe_material(self, mat, p):
+        p = np.ascontiguousarray(p, np.float64).reshape(-1, 3); col = np.zeros((len(p), 3)); ab = np.zeros(len(p))
+        self._check(self.L.rthip_probe_material(self.h, mat, len(p), _dp(p), _dp(col), _dp(ab)))
+        return col, ab
+
+    def probe_background(self, d):
+        d = np.ascontiguousarray(d, np.float64).reshape(-1, 3); col = np.zeros((len(d), 3))
+        self._check(self.L.rthip_probe_background(self.h, len(d), _dp(d), _dp(col)))
+        return col
+
+    def probe_raycast(self, o, d, max_recursion=3):
+        o = np.ascontiguousarray(o, np.float64).reshape(-1, 3); d = np.ascontiguousarray(d, np.float64).reshape(-1, 3)
+        col = np.zeros((len(o), 3))
+        self._check(self.L.rthip_probe_raycast(self.h, max_recursion, len(o), _dp(o), _dp(d), _dp(col)))
+        return col

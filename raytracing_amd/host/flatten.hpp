@@ -1,0 +1,36 @@
+// flatten.hpp — re::Scene (compiled) -> rthip_scene_desc POD blobs (include/rthip.h).
+// Runs at render start on the render thread, after Scene::Compile (reference Raytracer.cpp:42).
+#pragma once
+#include <string>
+#include <vector>
+
+#include "re/scene.hpp"
+#include "rthip.h"
+
+namespace re {
+
+struct FlatScene {
+    std::vector<rthip_shape> shapes;
+    std::vector<rthip_mesh> meshes;
+    std::vector<rthip_kdnode> kd_nodes;
+    std::vector<double> kd_bounds;
+    std::vector<uint32_t> kd_refs;
+    std::vector<rthip_tri> tris;
+    std::vector<double> tri_normals;
+    std::vector<rthip_matop> materials;
+    std::vector<rthip_noise> noises;
+    std::vector<uint8_t> perlin_tables;
+    std::vector<double> worley_points;
+    std::vector<rthip_light> lights;
+    rthip_scene_desc desc;
+    std::vector<SceneNode *> shape_nodes;  // pre-order shape ordinal -> node
+};
+
+// Returns 0 or RTHIP_E_UNSUPPORTED (user-defined Shape/Material/Noise/Background subclass, nesting
+// too deep, ...) with a message in `error`.  The scene must have been compiled.
+int FlattenScene(Scene *scene, FlatScene &out, std::string &error);
+
+// Camera basis of AbstractRaycaster::CreateScreenRay (Raytracer.cpp:102-110) computed once per frame.
+void MakeCamera(const Scene *scene, size_t width, size_t height, real fovY, rthip_camera &cam);
+
+}  // namespace re

@@ -1,0 +1,164 @@
+// hip_raytracer.cpp — re::HipRaytracer: the AbstractRaycaster subclass that replaces
+// re::Raytracer::Render (reference Raytracer/Raytracer.cpp:34-89) with the device path.
+// Contract kept: Render() returns immediately; work happens on a detached thread that first
+// compiles the scene; the promise is satisfied exactly once (also when interrupted) with
+// RenderStatus{Finished=true, Interruped, Percent, Pixels=m_Pixels}; GetStatus()/Interrupt() may
+// be called from another thread while rendering.  Device failures are delivered as
+// re::DeviceError through the promise — there is no CPU fallback.
+#include <chrono>
+#include <thread>
+
+#include "flatten.hpp"
+#include "re/renderer.hpp"
+#include "rthip.h"
+
+namespace re {
+
+unsigned int *Renderer::RenderSync(Scene *scene) {
+    std::promise<RenderStatus> p;
+    auto f = p.get_future();
+    Render(scene, std::move(p));
+    return f.get().Pixels;
+}
+
+AbstractRaycaster::AbstractRaycaster(unsigned int w, unsigned int h, real fovY) : Renderer(w, h, fovY) {
+    m_ColorBuffer0 = nullptr;
+    m_Pixels = new unsigned int[m_ViewWidth * m_ViewHeight]();
+}
+AbstractRaycaster::~AbstractRaycaster() { delete[] m_Pixels; }
+
+HipRaytracer::HipRaytracer(unsigned int w, unsigned int h, real fovY) : AbstractRaycaster(w, h, fovY) {}
+
+HipRaytracer::~HipRaytracer() {
+    {   // a detached render thread still uses *this: wait for it
+        std::unique_lock<std::mutex> lock(m_Mutex);
+        if (m_Busy && m_Ctx) rthip_interrupt(m_Ctx);
+        m_Idle.wait(lock, [this] { return !m_Busy; });
+    }
+    if (m_Ctx) rthip_destroy(m_Ctx);
+}
+
+Color HipRaytracer::Raycast(Scene *, const Ray &) {
+    throw DeviceError(RTHIP_E_UNSUPPORTED, "HipRaytracer shades whole frames on the device; per-ray host Raycast does not exist");
+}
+
+void HipRaytracer::Interrupt() {
+    m_Interrupted = true;  // Raytracer.cpp:91-94
+    std::lock_guard<std::mutex> lock(m_Mutex);
+    if (m_Busy && m_Ctx) rthip_interrupt(m_Ctx);
+}
+
+Renderer::RenderStatus HipRaytracer::GetStatus() {
+    RenderStatus s;
+    s.Finished = m_Finished;
+    s.Interruped = m_Interrupted;
+    s.Pixels = m_Pixels;
+    rthip_ctx *ctx;
+    {
+        std::lock_guard<std::mutex> lock(m_Mutex);
+        ctx = m_Ctx;
+    }
+    s.Percent = s.Finished ? (s.Interruped ? 0.f : 1.f) : (ctx ? rthip_progress(ctx) : 0.f);
+    return s;
+}
+
+HipRenderStats HipRaytracer::GetLastStats() {
+    std::lock_guard<std::mutex> lock(m_Mutex);
+    return m_Stats;
+}
+
+void HipRaytracer::Render(Scene *scene, std::promise<RenderStatus> p) {
+    {
+        std::unique_lock<std::mutex> lock(m_Mutex);
+        m_Idle.wait(lock, [this] { return !m_Busy; });  // one render at a time per renderer
+        m_Busy = true;
+    }
+    m_Finished = false;  // m_Status = { false, false, 0, m_Pixels }, Raytracer.cpp:36
+    m_Interrupted = false;
+    std::thread th(&HipRaytracer::RenderThread, this, scene, std::move(p));
+    th.detach();  // Raytracer.cpp:84-87
+}
+
+void HipRaytracer::RenderThread(Scene *scene, std::promise<RenderStatus> p) {
+    using clock = std::chrono::steady_clock;
+    auto ms = [](clock::time_point a, clock::time_point b) { return std::chrono::duration<float, std::milli>(b - a).count(); };
+    int rc = 0;
+    std::string err;
+    HipRenderStats stats;
+    try {
+        auto t0 = clock::now();
+        scene->Compile();  // Raytracer.cpp:42
+        FlatScene flat;
+        rc = FlattenScene(scene, flat, err);
+        auto t1 = clock::now();
+        stats.FlattenMs = ms(t0, t1);
+        if (!rc) {
+            std::lock_guard<std::mutex> lock(m_Mutex);
+            if (!m_Ctx) {
+                rc = rthip_create(Device, &m_Ctx);
+                if (rc) err = rthip_last_error();
+            }
+        }
+        if (!rc) {
+            rc = rthip_upload_scene(m_Ctx, &flat.desc);
+            if (rc) err = rthip_last_error();
+        }
+        auto t2 = clock::now();
+        stats.UploadMs = ms(t1, t2);
+        if (!rc && !m_Interrupted) {
+            rthip_camera cam;
+            MakeCamera(scene, m_ViewWidth, m_ViewHeight, m_FoVY, cam);
+            rthip_params prm;
+            prm.width = (uint32_t)m_ViewWidth;
+            prm.height = (uint32_t)m_ViewHeight;
+            prm.max_recursion = MaxRecursion;
+            prm.aa_mode = Antialiasing == AAMode::SSAA ? 1 : 0;
+            prm.renderer = RendererKind();
+            prm.part_index = PartIndex;
+            prm.part_count = PartCount;
+            prm.tile_w = TileWidth;
+            prm.tile_h = TileHeight;
+            rc = rthip_render(m_Ctx, &cam, &prm, m_Pixels, nullptr, nullptr);
+            if (rc == RTHIP_E_INTERRUPTED) {
+                m_Interrupted = true;
+                rc = 0;
+            } else if (rc) {
+                err = rthip_last_error();
+            } else {
+                rthip_stats st;
+                if (rthip_get_stats(m_Ctx, &st) == 0) {
+                    stats.RaysPrimary = st.rays_primary;
+                    stats.RaysShadow = st.rays_shadow;
+                    stats.RaysReflect = st.rays_reflect;
+                    stats.Pixels = st.pixels;
+                    stats.DeviceMs = st.ms_total;
+                }
+            }
+        }
+    } catch (const std::exception &e) {
+        rc = RTHIP_E_INVALID;
+        err = e.what();
+    }
+    RenderStatus status;
+    status.Interruped = m_Interrupted;
+    status.Percent = status.Interruped ? 0.f : 1.f;
+    status.Pixels = m_Pixels;
+    status.Finished = true;
+    {
+        std::lock_guard<std::mutex> lock(m_Mutex);
+        m_Stats = stats;
+    }
+    m_Finished = true;  // Raytracer.cpp:76-77
+    // release the renderer BEFORE publishing the result: the owner may destroy it as soon as the future is ready
+    {
+        std::lock_guard<std::mutex> lock(m_Mutex);
+        m_Busy = false;
+    }
+    m_Idle.notify_all();
+    if (rc)
+        p.set_exception(std::make_exception_ptr(DeviceError(rc, err)));
+    else
+        p.set_value(status);  // Raytracer.cpp:79
+}
+
+}  // namespace re

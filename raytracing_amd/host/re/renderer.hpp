@@ -1,0 +1,108 @@
+// re/renderer.hpp — renderer side of the re:: host mirror (reference Raytracer/Raytracer.h:16-135).
+// Renderer and AbstractRaycaster keep the reference's public surface; HipRaytracer is the new
+// AbstractRaycaster subclass that is the drop-in for re::Raytracer: Render() returns at once, a
+// detached thread compiles the scene, flattens it, and renders the frame on the MI355X through
+// the C-ABI in include/rthip.h.  There is no CPU rendering path in this library.
+#pragma once
+#include <atomic>
+#include <condition_variable>
+#include <future>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+
+#include "scene.hpp"
+
+struct rthip_ctx;
+
+namespace re {
+
+class Renderer {  // Raytracer.h:16-51
+public:
+    struct RenderStatus {
+        bool Finished;
+        bool Interruped;
+        float Percent;
+        unsigned int *Pixels;
+    };
+    Renderer(size_t viewWidth, size_t viewHeight, real fovY = PI / 4) : m_ViewWidth(viewWidth), m_ViewHeight(viewHeight), m_FoVY(fovY) {}
+    virtual ~Renderer() {}
+    // Render + wait (Raytracer.cpp:12-18); rethrows a device error delivered through the promise
+    virtual unsigned int *RenderSync(Scene *scene);
+    virtual void Render(Scene *scene, std::promise<RenderStatus> promise) = 0;
+    virtual RenderStatus GetStatus() = 0;
+    virtual void Interrupt() = 0;
+    virtual size_t GetViewWidth() { return m_ViewWidth; }
+    virtual size_t GetViewHeight() { return m_ViewHeight; }
+protected:
+    size_t m_ViewWidth, m_ViewHeight;
+    real m_FoVY;
+};
+
+class AbstractRaycaster : public Renderer {  // Raytracer.h:55-98
+public:
+    enum class AAMode : int { None = 0, SSAA = 1 };
+    AbstractRaycaster(unsigned int viewWidth, unsigned int viewHeight, real fovY = PI / 4.0f);
+    ~AbstractRaycaster() override;
+    AAMode Antialiasing = AAMode::None;
+    unsigned int NumThreads = 4;  // kept for source compatibility; the device path ignores it
+protected:
+    virtual Color Raycast(Scene *scene, const Ray &ray) = 0;
+    Color *m_ColorBuffer0;   // not allocated: the fp64 colour buffer lives in HBM (rec level 0)
+    unsigned int *m_Pixels;  // W*H, index y*W+x, 0xAABBGGRR
+};
+
+// Error delivered through the promise / RenderSync when the device path cannot run (additive:
+// the reference has no error channel, SURVEY.md §8b "errors").
+class DeviceError : public std::runtime_error {
+public:
+    DeviceError(int code, const std::string &what) : std::runtime_error(what), Code(code) {}
+    int Code;
+};
+
+struct HipRenderStats {
+    unsigned long long RaysPrimary = 0, RaysShadow = 0, RaysReflect = 0, Pixels = 0;
+    float DeviceMs = 0.f;     // HIP-event time of the frame's kernels
+    float FlattenMs = 0.f;    // host: Scene::Compile + flatten
+    float UploadMs = 0.f;     // host->device scene upload
+};
+
+class HipRaytracer : public AbstractRaycaster {  // drop-in for re::Raytracer (Raytracer.h:100-116)
+public:
+    unsigned int MaxRecursion = 3;
+    // additive knobs
+    int Device = 0;                         // HIP device ordinal of this process
+    unsigned int PartIndex = 0, PartCount = 1;  // interleaved-tile share rendered by this process
+    unsigned int TileWidth = 32, TileHeight = 8;
+
+    HipRaytracer(unsigned int viewWidth, unsigned int viewHeight, real fovY = PI / 4.0f);
+    ~HipRaytracer() override;
+
+    void Render(Scene *scene, std::promise<RenderStatus> p) override;
+    void Interrupt() override;
+    RenderStatus GetStatus() override;
+    HipRenderStats GetLastStats();
+protected:
+    // The abstract base requires it; the device path shades whole frames, never single rays on the host.
+    Color Raycast(Scene *scene, const Ray &ray) override;
+    virtual int RendererKind() const { return 0; }  // RTHIP_RENDER_RAYTRACER
+private:
+    void RenderThread(Scene *scene, std::promise<RenderStatus> p);
+    rthip_ctx *m_Ctx = nullptr;
+    std::mutex m_Mutex;
+    std::condition_variable m_Idle;
+    bool m_Busy = false;
+    std::atomic<bool> m_Finished{true}, m_Interrupted{true};
+    HipRenderStats m_Stats;
+};
+
+class HipDebugRaycaster : public HipRaytracer {  // drop-in for re::DebugRaycaster (Raytracer.h:119-135)
+public:
+    enum class Modes : unsigned int { Normal = 0, Color = 1 };
+    Modes Mode = Modes::Normal;
+    HipDebugRaycaster(unsigned int w, unsigned int h, real fovY = PI / 4.0f) : HipRaytracer(w, h, fovY) {}
+protected:
+    int RendererKind() const override { return 1 + (int)Mode; }
+};
+
+}  // namespace re
