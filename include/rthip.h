@@ -172,6 +172,10 @@ typedef struct {
      * tiles of tile_w x tile_h pixels) with t % part_count == part_index.  part_count = 1 -> whole frame. */
     uint32_t part_index, part_count;
     uint32_t tile_w, tile_h;  /* 0 -> default 32 x 8 */
+    /* rthip_render_device only: 0 = d_pixels is the width*height frame (row-major);
+     * 1 = d_pixels is this part's tile-compact buffer: rthip_part_pixels() uint32, tile after tile in
+     * this part's tile order, 8x8 sub-blocks inside a tile (what the multi-GPU gather ships) */
+    int32_t layout;
 } rthip_params;
 
 typedef struct {
@@ -181,7 +185,13 @@ typedef struct {
     float ms_trace;                                    /* summed duration of the trace/shade kernels */
     uint32_t launches_trace;                           /* number of trace/shade kernel launches */
     uint32_t pad;
-    uint64_t kd_nodes_visited, kd_tris_tested, kd_leaves_visited; /* only with RTHIP_COUNTERS=1 builds/contexts */
+    /* only collected by contexts created with RTHIP_COUNTERS=1 in the environment: */
+    uint64_t kd_nodes_visited;   /* kd node records fetched (16 B each) */
+    uint64_t kd_tris_tested;     /* triangle records tested (128 B + 4 B reference each) */
+    uint64_t kd_leaves_visited;
+    uint64_t kd_pops;            /* pending subtrees resumed (48 B of bounds each) */
+    uint64_t shape_tests;        /* shape-table entries tested (world->local transform fetch) */
+    uint64_t mesh_hits;          /* mesh hits whose vertex normals were fetched (72 B) */
 } rthip_stats;
 
 /* ---- lifecycle ---- */
@@ -208,6 +218,13 @@ int rthip_render(rthip_ctx *ctx, const rthip_camera *cam, const rthip_params *pa
  * context's stream unless `sync` is non-zero.  Used by bench.py and the multi-GPU gather. */
 int rthip_render_device(rthip_ctx *ctx, const rthip_camera *cam, const rthip_params *params,
                         void *d_pixels, int sync);
+/* number of uint32 entries of one part's tile-compact buffer (identical for every part_index:
+ * ceil(n_tiles / part_count) * tile_w * tile_h), 0 on bad params */
+uint64_t rthip_part_pixels(const rthip_params *params);
+/* replaces: nothing in the reference (single process); multi-GPU only.  d_gathered holds
+ * part_count tile-compact buffers of rthip_part_pixels() entries each, part after part (the result
+ * of an all-gather / gather over RCCL); writes the width*height row-major frame to d_frame. */
+int rthip_assemble(rthip_ctx *ctx, const rthip_params *params, const void *d_gathered, void *d_frame, int sync);
 /* HIP stream the context launches on (hipStream_t as void*), so callers can order work after it */
 void *rthip_stream(rthip_ctx *ctx);
 int rthip_synchronize(rthip_ctx *ctx);

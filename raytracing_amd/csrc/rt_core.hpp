@@ -72,7 +72,7 @@ struct KdStack {
 };
 
 struct KdCounters {
-    uint32_t nodes, leaves, tris;
+    uint32_t nodes, leaves, tris, pops, shapes, mesh_hits;
 };
 
 // ----------------------------------------------------------------------------- math (C1)
@@ -388,12 +388,13 @@ RT_HD void mesh_closest(const SceneView &sv, const rthip_mesh &m, V3 o, V3 d, Kd
     const rthip_tri *tris = sv.tris + m.tri_base;
     double t[6], t7;
     slab_params(bounds, o, d, t);
-    if (cnt) cnt->nodes++;
+    if (cnt) cnt->pops++;
     if (!slab_hit(t, t7)) return;
     st.clear();
     uint32_t cur = 0;
     for (;;) {
         rthip_kdnode nd = nodes[cur];
+        if (cnt) cnt->nodes++;
         bool descend = false;
         if (nd.info & RTHIP_KD_LEAF) {
             uint32_t count = nd.info >> RTHIP_KD_COUNT_SHIFT;
@@ -420,7 +421,6 @@ RT_HD void mesh_closest(const SceneView &sv, const rthip_mesh &m, V3 o, V3 d, Kd
             }
             bool hl = (nd.info & RTHIP_KD_HAS_LEFT) && slab_hit(tl, t7l) && !kd_prunable(t7l, best);
             bool hr = (nd.info & RTHIP_KD_HAS_RIGHT) && slab_hit(tr, t7r) && !kd_prunable(t7r, best);
-            if (cnt) cnt->nodes += ((nd.info & RTHIP_KD_HAS_LEFT) ? 1 : 0) + ((nd.info & RTHIP_KD_HAS_RIGHT) ? 1 : 0);
             if (hl && hr) {
                 bool left_first = t7l <= t7r;
                 st.push(left_first ? nd.link : cur + 1);
@@ -445,6 +445,7 @@ RT_HD void mesh_closest(const SceneView &sv, const rthip_mesh &m, V3 o, V3 d, Kd
         bool found = false;
         while (!st.empty()) {
             cur = st.pop();
+            if (cnt) cnt->pops++;
             slab_params(bounds + 6 * (size_t)cur, o, d, t);
             if (slab_hit(t, t7) && !kd_prunable(t7, best)) {
                 found = true;
@@ -475,6 +476,7 @@ RT_HD Hit cast_ray(const SceneView &sv, V3 o, V3 d, KdStack &st, bool any_hit, K
     V3 best_local_normal = mk(0, 0, 0);
     for (uint32_t s = 0; s < sv.n_shapes; s++) {
         const rthip_shape &sh = sv.shapes[s];
+        if (cnt) cnt->shapes++;
         V3 lo = xform(sh.inv, o, 1.0);
         V3 ld = normalized(xform(sh.inv, d, 0.0));
         V3 p = mk(0, 0, 0), ln = mk(0, 0, 0);
@@ -512,6 +514,7 @@ RT_HD Hit cast_ray(const SceneView &sv, V3 o, V3 d, KdStack &st, bool any_hit, K
                 const rthip_tri &t = sv.tris[m.tri_base + tb.tri];
                 ln = mk(t.face_normal[0], t.face_normal[1], t.face_normal[2]);  // Scene.cpp:458
             } else {  // Scene.cpp:462
+                if (cnt) cnt->mesh_hits++;
                 const double *n = sv.tri_normals + 9 * (size_t)(m.tri_base + tb.tri);
                 ln = normalized(add(add(scale(mk(n[0], n[1], n[2]), tb.u), scale(mk(n[3], n[4], n[5]), tb.v)),
                                     scale(mk(n[6], n[7], n[8]), tb.w)));

@@ -65,7 +65,7 @@ struct DevBuf {
 
 static const uint32_t kBlock = 256;           // 4 waves per workgroup
 static const uint32_t kMaxGridLevel = 4096;   // queue levels: grid-stride over a bounded grid
-enum { ST_PRIMARY = 0, ST_SHADOW, ST_REFLECT, ST_KD_NODES, ST_KD_TRIS, ST_KD_LEAVES, ST_COUNT };
+enum { ST_PRIMARY = 0, ST_SHADOW, ST_REFLECT, ST_KD_NODES, ST_KD_TRIS, ST_KD_LEAVES, ST_KD_POPS, ST_SHAPES, ST_MESH_HITS, ST_COUNT };
 
 // Per-frame constants
 struct FrameParams {
@@ -77,6 +77,7 @@ struct FrameParams {
     uint32_t n_pix_slots;  // tile slots in this chunk * tile_w * tile_h
     uint32_t N0;           // level-0 rays of this chunk = n_pix_slots * (aa ? 9 : 1)
     uint32_t count_kd;     // collect kd counters
+    int32_t layout;        // 0 frame, 1 tile-compact
 };
 // Per-frame device workspace (struct-of-arrays; N = capacity of one level)
 struct Work {
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(kBlock) void k_bounce(SceneView sv, FrameParams fp,
     const uint32_t n = (level == 0) ? fp.N0 : w.counts[level];
     const uint32_t lane = threadIdx.x & 63u;
     uint32_t shadow_total = 0, spawn_total = 0;
-    KdCounters kc = {0, 0, 0};
+    KdCounters kc = {0, 0, 0, 0, 0, 0};
     KdCounters *kcp = fp.count_kd ? &kc : nullptr;
     for (uint32_t base = blockIdx.x * kBlock; base < n; base += gridDim.x * kBlock) {
         uint32_t i = base + threadIdx.x;
@@ -205,6 +206,9 @@ __global__ __launch_bounds__(kBlock) void k_bounce(SceneView sv, FrameParams fp,
         kc.nodes = wave_sum(kc.nodes);
         kc.tris = wave_sum(kc.tris);
         kc.leaves = wave_sum(kc.leaves);
+        kc.pops = wave_sum(kc.pops);
+        kc.shapes = wave_sum(kc.shapes);
+        kc.mesh_hits = wave_sum(kc.mesh_hits);
     }
     if (lane == 0) {
         if (shadow_total) atomicAdd(&w.stats[ST_SHADOW], (unsigned long long)shadow_total);
@@ -213,6 +217,9 @@ __global__ __launch_bounds__(kBlock) void k_bounce(SceneView sv, FrameParams fp,
             atomicAdd(&w.stats[ST_KD_NODES], (unsigned long long)kc.nodes);
             atomicAdd(&w.stats[ST_KD_TRIS], (unsigned long long)kc.tris);
             atomicAdd(&w.stats[ST_KD_LEAVES], (unsigned long long)kc.leaves);
+            atomicAdd(&w.stats[ST_KD_POPS], (unsigned long long)kc.pops);
+            atomicAdd(&w.stats[ST_SHAPES], (unsigned long long)kc.shapes);
+            atomicAdd(&w.stats[ST_MESH_HITS], (unsigned long long)kc.mesh_hits);
         }
     }
 }
@@ -250,10 +257,23 @@ __global__ __launch_bounds__(kBlock) void k_resolve(FrameParams fp, Work w, uint
     } else {
         c = Col{rec_ptr(w, 0, 0)[ps], rec_ptr(w, 0, 1)[ps], rec_ptr(w, 0, 2)[ps]};
     }
-    size_t idx = (size_t)y * fp.W + x;
+    size_t idx = fp.layout ? (size_t)fp.q0 * fp.tile_w * fp.tile_h + ps : (size_t)y * fp.W + x;
     pixels[idx] = c_pack(c);
     if (out_shape) out_shape[idx] = w.id_shape[ps];
     if (out_tri) out_tri[idx] = w.id_tri[ps];
+}
+
+// multi-GPU: part_count tile-compact buffers (part after part) -> row-major frame
+__global__ __launch_bounds__(kBlock) void k_assemble(FrameParams fp, const uint32_t *gathered, uint32_t part_slots,
+                                                     uint32_t *frame) {
+    uint32_t ps = blockIdx.x * kBlock + threadIdx.x;
+    uint32_t part = blockIdx.y;
+    if (ps >= part_slots) return;
+    fp.part_index = part;
+    fp.q0 = 0;
+    uint32_t x, y;
+    if (!slot_to_pixel(fp, ps, x, y)) return;
+    frame[(size_t)y * fp.W + x] = gathered[(size_t)part * part_slots + ps];
 }
 
 // ---- probe kernels (KAT parity of single device functions) ----
@@ -547,6 +567,7 @@ static int check_params(const rthip_camera *cam, const rthip_params *p) {
     if (p->part_count == 0 || p->part_index >= p->part_count) return fail(RTHIP_E_INVALID, "rthip_render: part %u of %u", p->part_index, p->part_count);
     uint32_t tw = p->tile_w ? p->tile_w : 32, th = p->tile_h ? p->tile_h : 8;
     if (tw % 8 || th % 8 || tw > 1024 || th > 1024) return fail(RTHIP_E_INVALID, "rthip_render: tile %ux%u must be multiples of 8", tw, th);
+    if (p->layout != 0 && p->layout != 1) return fail(RTHIP_E_INVALID, "rthip_render: layout %d", p->layout);
     return 0;
 }
 
@@ -575,6 +596,7 @@ static int render_frame(rthip_ctx *c, const rthip_camera *cam, const rthip_param
     fp.tiles_x = (fp.W + fp.tile_w - 1) / fp.tile_w;
     fp.tiles_y = (fp.H + fp.tile_h - 1) / fp.tile_h;
     fp.count_kd = c->count_kd;
+    fp.layout = (d_shape || d_tri) ? 0 : p->layout;
     const uint32_t n_tiles = fp.tiles_x * fp.tiles_y;
     const uint32_t my_tiles = n_tiles > fp.part_index ? (n_tiles - fp.part_index + fp.part_count - 1) / fp.part_count : 0;
     const uint32_t per_tile = fp.tile_w * fp.tile_h;
@@ -685,6 +707,9 @@ static int finish_stats(rthip_ctx *c, const rthip_params *p) {
     c->last.kd_nodes_visited = st[ST_KD_NODES];
     c->last.kd_tris_tested = st[ST_KD_TRIS];
     c->last.kd_leaves_visited = st[ST_KD_LEAVES];
+    c->last.kd_pops = st[ST_KD_POPS];
+    c->last.shape_tests = st[ST_SHAPES];
+    c->last.mesh_hits = st[ST_MESH_HITS];
     c->last.ms_total = ms;
     float sum = 0.f;
     for (uint32_t i = 0; i < c->last.launches_trace; i++) {
@@ -722,13 +747,46 @@ int rthip_render(rthip_ctx *c, const rthip_camera *cam, const rthip_params *p, u
         HIP_TRY(hipMemcpyAsync(d_px, out_pixels, sizeof(uint32_t) * npx, hipMemcpyHostToDevice, c->stream));
     }
     if (ids) HIP_TRY(hipMemsetAsync(d_sh, 0xff, sizeof(int32_t) * 2 * npx, c->stream));
-    rc = render_frame(c, cam, p, d_px, d_sh, d_tr);
+    rthip_params pf = *p;
+    pf.layout = 0;
+    rc = render_frame(c, cam, &pf, d_px, d_sh, d_tr);
     if (rc) return rc;
     rc = finish_stats(c, p);
     if (rc) return rc;
     HIP_TRY(hipMemcpy(out_pixels, d_px, sizeof(uint32_t) * npx, hipMemcpyDeviceToHost));
     if (out_shape) HIP_TRY(hipMemcpy(out_shape, d_sh, sizeof(int32_t) * npx, hipMemcpyDeviceToHost));
     if (out_tri) HIP_TRY(hipMemcpy(out_tri, d_tr, sizeof(int32_t) * npx, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+uint64_t rthip_part_pixels(const rthip_params *p) {
+    if (!p || p->width == 0 || p->height == 0 || p->part_count == 0) return 0;
+    uint32_t tw = p->tile_w ? p->tile_w : 32, th = p->tile_h ? p->tile_h : 8;
+    uint64_t tiles = (uint64_t)((p->width + tw - 1) / tw) * ((p->height + th - 1) / th);
+    return ((tiles + p->part_count - 1) / p->part_count) * tw * th;
+}
+
+int rthip_assemble(rthip_ctx *c, const rthip_params *p, const void *d_gathered, void *d_frame, int sync) {
+    if (!c || !p || !d_gathered || !d_frame) return fail(RTHIP_E_INVALID, "rthip_assemble: null argument");
+    rthip_camera dummy;
+    memset(&dummy, 0, sizeof dummy);
+    int rc = check_params(&dummy, p);
+    if (rc) return rc;
+    if (set_device(c)) return RTHIP_E_HIP;
+    FrameParams fp;
+    memset(&fp, 0, sizeof fp);
+    fp.W = p->width;
+    fp.H = p->height;
+    fp.part_count = p->part_count;
+    fp.tile_w = p->tile_w ? p->tile_w : 32;
+    fp.tile_h = p->tile_h ? p->tile_h : 8;
+    fp.tiles_x = (fp.W + fp.tile_w - 1) / fp.tile_w;
+    fp.tiles_y = (fp.H + fp.tile_h - 1) / fp.tile_h;
+    uint32_t part_slots = (uint32_t)rthip_part_pixels(p);
+    hipLaunchKernelGGL(k_assemble, dim3((part_slots + kBlock - 1) / kBlock, p->part_count), dim3(kBlock), 0, c->stream, fp,
+                       (const uint32_t *)d_gathered, part_slots, (uint32_t *)d_frame);
+    HIP_TRY(hipGetLastError());
+    if (sync) HIP_TRY(hipStreamSynchronize(c->stream));
     return 0;
 }
 

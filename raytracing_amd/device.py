@@ -17,7 +17,8 @@ c_u32p = C.POINTER(C.c_uint32)
 SYMBOLS = ["rthip_create", "rthip_destroy", "rthip_last_error", "rthip_upload_scene", "rthip_render",
            "rthip_render_device", "rthip_stream", "rthip_synchronize", "rthip_progress", "rthip_interrupt",
            "rthip_get_stats", "rthip_probe_cast", "rthip_probe_noise", "rthip_probe_material",
-           "rthip_probe_background", "rthip_probe_raycast", "rthip_probe_arith", "rthip_version"]
+           "rthip_probe_background", "rthip_probe_raycast", "rthip_probe_arith", "rthip_version",
+           "rthip_part_pixels", "rthip_assemble"]
 
 
 class Camera(C.Structure):
@@ -28,14 +29,15 @@ class Camera(C.Structure):
 class Params(C.Structure):
     _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("max_recursion", C.c_uint32),
                 ("aa_mode", C.c_int32), ("renderer", C.c_int32), ("part_index", C.c_uint32),
-                ("part_count", C.c_uint32), ("tile_w", C.c_uint32), ("tile_h", C.c_uint32)]
+                ("part_count", C.c_uint32), ("tile_w", C.c_uint32), ("tile_h", C.c_uint32), ("layout", C.c_int32)]
 
 
 class Stats(C.Structure):
     _fields_ = [("rays_primary", C.c_uint64), ("rays_shadow", C.c_uint64), ("rays_reflect", C.c_uint64),
                 ("pixels", C.c_uint64), ("ms_total", C.c_float), ("ms_trace", C.c_float),
                 ("launches_trace", C.c_uint32), ("pad", C.c_uint32), ("kd_nodes_visited", C.c_uint64),
-                ("kd_tris_tested", C.c_uint64), ("kd_leaves_visited", C.c_uint64)]
+                ("kd_tris_tested", C.c_uint64), ("kd_leaves_visited", C.c_uint64), ("kd_pops", C.c_uint64),
+                ("shape_tests", C.c_uint64), ("mesh_hits", C.c_uint64)]
 
 
 class RthipError(RuntimeError):
@@ -64,6 +66,9 @@ def lib():
     L.rthip_upload_scene.argtypes = [vp, vp]
     L.rthip_render.argtypes = [vp, C.POINTER(Camera), C.POINTER(Params), c_u32p, c_i32p, c_i32p]
     L.rthip_render_device.argtypes = [vp, C.POINTER(Camera), C.POINTER(Params), vp, C.c_int]
+    L.rthip_part_pixels.argtypes = [C.POINTER(Params)]
+    L.rthip_part_pixels.restype = C.c_uint64
+    L.rthip_assemble.argtypes = [vp, C.POINTER(Params), vp, vp, C.c_int]
     L.rthip_stream.argtypes = [vp]
     L.rthip_stream.restype = vp
     L.rthip_synchronize.argtypes = [vp]
@@ -85,8 +90,12 @@ def _dp(a):
     return None if a is None else a.ctypes.data_as(c_dp)
 
 
-def make_params(width, height, max_recursion=3, aa=0, renderer=0, part_index=0, part_count=1, tile_w=0, tile_h=0):
-    return Params(width, height, max_recursion, aa, renderer, part_index, part_count, tile_w, tile_h)
+def make_params(width, height, max_recursion=3, aa=0, renderer=0, part_index=0, part_count=1, tile_w=0, tile_h=0, layout=0):
+    return Params(width, height, max_recursion, aa, renderer, part_index, part_count, tile_w, tile_h, layout)
+
+
+def part_pixels(params):
+    return int(lib().rthip_part_pixels(C.byref(params)))
 
 
 class Context:
@@ -130,6 +139,9 @@ class Context:
 
     def render_device(self, cam, params, d_pixels_ptr, sync=False):
         self._check(self.L.rthip_render_device(self.h, C.byref(cam), C.byref(params), C.c_void_p(d_pixels_ptr), int(sync)))
+
+    def assemble(self, params, d_gathered_ptr, d_frame_ptr, sync=False):
+        self._check(self.L.rthip_assemble(self.h, C.byref(params), C.c_void_p(d_gathered_ptr), C.c_void_p(d_frame_ptr), int(sync)))
 
     def synchronize(self):
         self._check(self.L.rthip_synchronize(self.h))

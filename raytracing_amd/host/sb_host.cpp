@@ -4,6 +4,7 @@
 // rendered by re::HipRaytracer::RenderSync, and the probe calls go through the rthip_* C-ABI.
 // Nothing here evaluates rays on the host.
 #include <cstring>
+#include <functional>
 #include <memory>
 #include <string>
 #include <vector>
