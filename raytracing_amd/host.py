@@ -29,6 +29,12 @@ def load_host():
         L.rehost_shape_ordinal.argtypes = [C.c_void_p, C.c_int]
         L.rehost_last_stats.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
         L.rehost_last_error.restype = C.c_char_p
+        from .sbapi import RenderParams
+        L.rehost_render_async.argtypes = [C.c_void_p, C.POINTER(RenderParams)]; L.rehost_render_async.restype = C.c_void_p
+        L.rehost_job_status.argtypes = [C.c_void_p, C.POINTER(C.c_float)]; L.rehost_job_status.restype = None
+        L.rehost_job_interrupt.argtypes = [C.c_void_p]; L.rehost_job_interrupt.restype = None
+        L.rehost_job_wait.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]
+        L.rehost_job_free.argtypes = [C.c_void_p]; L.rehost_job_free.restype = None
         _host = sb
     return _host
 
@@ -67,3 +73,34 @@ class HostScene:
         self.L.rehost_last_stats(self.h, out)
         keys = ["rays_primary", "rays_shadow", "rays_reflect", "pixels", "device_ms", "flatten_ms", "upload_ms"]
         return dict(zip(keys, list(out)))
+
+
+class RenderJob:
+    """Asynchronous re::HipRaytracer::Render (returns at once; status can be polled; can be interrupted)."""
+
+    def __init__(self, hs, width, height, max_recursion=3, aa=0):
+        from .sbapi import RenderParams
+        self.hs, self.w, self.h = hs, width, height
+        p = RenderParams(width, height, 0.0, max_recursion, aa, 1, 0)
+        self.j = hs.L.rehost_render_async(hs.h, C.byref(p))
+
+    def status(self):
+        out = (C.c_float * 4)()
+        self.hs.L.rehost_job_status(self.j, out)
+        return {"finished": bool(out[0]), "interrupted": bool(out[1]), "percent": float(out[2]), "has_pixels": bool(out[3])}
+
+    def interrupt(self):
+        self.hs.L.rehost_job_interrupt(self.j)
+
+    def wait(self):
+        px = np.zeros((self.h, self.w), np.uint32)
+        out = (C.c_float * 3)()
+        rc = self.hs.L.rehost_job_wait(self.j, px.ctypes.data_as(C.c_void_p), out)
+        if rc != 0:
+            raise RuntimeError(f"render failed ({rc}): " + self.hs.L.rehost_last_error().decode())
+        return px, {"finished": bool(out[0]), "interrupted": bool(out[1]), "percent": float(out[2])}
+
+    def close(self):
+        if self.j:
+            self.hs.L.rehost_job_free(self.j)
+            self.j = None

@@ -5,6 +5,7 @@
 // Nothing here evaluates rays on the host.
 #include <cstring>
 #include <functional>
+#include <future>
 #include <memory>
 #include <string>
 #include <vector>
@@ -52,6 +53,12 @@ static int ensure_device(sb_scene *s) {
     }
     return 0;
 }
+
+struct sb_render_params {
+    int width, height;
+    double fovy;
+    int max_recursion, aa_mode, num_threads, renderer;
+};
 
 extern "C" {
 
@@ -215,11 +222,6 @@ int rehost_last_stats(sb_scene *s, double *out8) {
     return 0;
 }
 
-struct sb_render_params {
-    int width, height;
-    double fovy;
-    int max_recursion, aa_mode, num_threads, renderer;
-};
 
 // Whole frame through the drop-in class: HipRaytracer / HipDebugRaycaster ::RenderSync.
 // Primary-hit ids (optional) come from a second, id-only device pass through rthip_render.
@@ -281,6 +283,50 @@ int sb_render(sb_scene *s, const sb_render_params *p, uint32_t *pixels, int32_t 
         return RTHIP_E_INVALID;
     }
 }
+
+// ---- asynchronous contract of Renderer::Render / GetStatus / Interrupt (Raytracer.h:36-43) ----
+struct rehost_job {
+    std::unique_ptr<HipRaytracer> rt;
+    std::future<Renderer::RenderStatus> fut;
+    int width = 0, height = 0;
+};
+rehost_job *rehost_render_async(sb_scene *s, const sb_render_params *p) {
+    auto *j = new rehost_job;
+    j->rt.reset(new HipRaytracer(p->width, p->height, p->fovy > 0 ? p->fovy : PI / 4));
+    j->rt->MaxRecursion = p->max_recursion;
+    j->rt->Device = s->device;
+    j->rt->Antialiasing = p->aa_mode == 1 ? AbstractRaycaster::AAMode::SSAA : AbstractRaycaster::AAMode::None;
+    j->width = p->width;
+    j->height = p->height;
+    std::promise<Renderer::RenderStatus> pr;
+    j->fut = pr.get_future();
+    s->compiled = false;
+    s->uploaded = false;
+    j->rt->Render(s->scene.get(), std::move(pr));  // returns immediately
+    return j;
+}
+// out4: Finished, Interruped, Percent, (Pixels != null)
+void rehost_job_status(rehost_job *j, float *out4) {
+    Renderer::RenderStatus st = j->rt->GetStatus();
+    out4[0] = st.Finished; out4[1] = st.Interruped; out4[2] = st.Percent; out4[3] = st.Pixels != nullptr;
+}
+void rehost_job_interrupt(rehost_job *j) { j->rt->Interrupt(); }
+// waits for the promise; returns 0 and copies the pixels, or the DeviceError code. out3: Finished, Interruped, Percent
+int rehost_job_wait(rehost_job *j, uint32_t *pixels, float *out3) {
+    try {
+        Renderer::RenderStatus st = j->fut.get();
+        if (out3) { out3[0] = st.Finished; out3[1] = st.Interruped; out3[2] = st.Percent; }
+        if (pixels && st.Pixels) std::memcpy(pixels, st.Pixels, sizeof(uint32_t) * (size_t)j->width * j->height);
+        return 0;
+    } catch (const DeviceError &e) {
+        g_host_err = e.what();
+        return e.Code;
+    } catch (const std::exception &e) {
+        g_host_err = e.what();
+        return RTHIP_E_INVALID;
+    }
+}
+void rehost_job_free(rehost_job *j) { delete j; }
 
 int sb_cast_rays(sb_scene *s, int n, const double *o, const double *d, int32_t *out_hit, double *out_point,
                  double *out_local, double *out_normal, int32_t *out_shape, int32_t *out_tri) {

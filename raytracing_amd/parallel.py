@@ -1,0 +1,51 @@
+"""Screen partition used by the multi-GPU path, restated on the host with numpy: interleaved
+tile_w x tile_h tiles (tile t -> part t % part_count), 8x8 sub-blocks inside a tile — the same
+slot order the device writes with rthip_params.layout = 1 and reads in rthip_assemble (k_assemble).
+Used by the CPU (gloo) tests and as documentation of the layout; the GPU path gathers with
+torch.distributed (RCCL) and assembles on the device."""
+import numpy as np
+
+
+def _slot_xy(w, h, part, part_count, tile_w=32, tile_h=8):
+    """(x, y, valid) for every slot of `part`'s tile-compact buffer."""
+    tiles_x, tiles_y = -(-w // tile_w), -(-h // tile_h)
+    n_tiles = tiles_x * tiles_y
+    per_tile = tile_w * tile_h
+    part_tiles = -(-n_tiles // part_count)
+    slot = np.arange(part_tiles * per_tile, dtype=np.int64)
+    q, r = slot // per_tile, slot % per_tile
+    t = part + q * part_count
+    tx, ty = t % tiles_x, t // tiles_x
+    sb, l = r >> 6, r & 63
+    sbx = tile_w >> 3
+    x = tx * tile_w + (sb % sbx) * 8 + (l & 7)
+    y = ty * tile_h + (sb // sbx) * 8 + (l >> 3)
+    valid = (t < n_tiles) & (x < w) & (y < h)
+    return x, y, valid
+
+
+def part_slots(w, h, part_count, tile_w=32, tile_h=8):
+    return -(-(-(-w // tile_w) * -(-h // tile_h)) // part_count) * tile_w * tile_h
+
+
+def frame_to_part(frame, part, part_count, tile_w=32, tile_h=8):
+    h, w = frame.shape
+    x, y, valid = _slot_xy(w, h, part, part_count, tile_w, tile_h)
+    out = np.zeros(len(x), dtype=frame.dtype)
+    out[valid] = frame[y[valid], x[valid]]
+    return out
+
+
+def assemble_parts(parts, w, h, tile_w=32, tile_h=8):
+    part_count = parts.shape[0]
+    frame = np.zeros((h, w), dtype=parts.dtype)
+    for p in range(part_count):
+        x, y, valid = _slot_xy(w, h, p, part_count, tile_w, tile_h)
+        frame[y[valid], x[valid]] = parts[p][valid]
+    return frame
+
+
+def pixel_owner(w, h, part_count, tile_w=32, tile_h=8):
+    tiles_x = -(-w // tile_w)
+    ys, xs = np.mgrid[0:h, 0:w]
+    return ((ys // tile_h) * tiles_x + xs // tile_w) % part_count

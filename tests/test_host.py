@@ -1,0 +1,109 @@
+"""CPU: host logic of the product (re:: mirror Compile(), kd build, flattener) and the device core compiled
+for the host (tests/hostcore), against the golden vectors; plus the C-ABI export check."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import FRAME_CASES, KAT_SCENES, ROOT
+from raytracing_amd import device, host, scenes
+
+
+def test_c_abi_library_loads_and_exports_every_declared_symbol(host_lib):
+    header = open(os.path.join(ROOT, "include", "rthip.h")).read()
+    declared = sorted(set(re.findall(r"\b(rthip_[a-z_]+)\s*\(", header)))
+    assert declared, "no declarations found"
+    assert sorted(device.SYMBOLS) == declared
+    L = device.lib()
+    for name in declared:
+        assert hasattr(L, name), name
+    assert b"gfx950" in L.rthip_version()
+    prm = device.make_params(1920, 1080, part_count=8)
+    assert device.part_pixels(prm) == ((60 * 135 + 7) // 8) * 256  # no compute call: pure host helper
+    assert not host_lib.missing or host_lib.missing == []
+
+
+def test_host_kdtree_is_the_reference_tree(host_lib, golden):
+    hs = host.HostScene(scenes.config(3)[0])
+    kd = hs.built.kd_dump(2)
+    g = golden["bunny_kd"]
+    for key in ("depth", "ntris", "split", "bounds", "refs"):
+        assert np.array_equal(kd[key], g[key]), key
+
+
+@pytest.mark.parametrize("name", list(KAT_SCENES))
+def test_host_transforms_match_reference(host_lib, golden, name):
+    sd = KAT_SCENES[name]()
+    hs = host.HostScene(sd)
+    for node in range(1, sd._n["node"]):
+        assert np.array_equal(hs.built.node_matrices(node), golden["kat"][f"{name}_node{node}_matrices"])
+
+
+def _hostcore():
+    L = C.CDLL(os.path.join(ROOT, "tests", "hostcore", "libhostcore.so"))
+    return L
+
+
+@pytest.mark.parametrize("name", list(FRAME_CASES))
+def test_flattener_plus_device_core_on_host_match_golden(host_lib, golden, name):
+    """the flattened scene (product host code) rendered by rt_core.hpp compiled with g++ (test build)"""
+    mk, w, h, kw = FRAME_CASES[name]
+    hs = host.HostScene(mk())
+    cam = hs.camera(w, h)
+    prm = device.make_params(w, h, kw.get("max_recursion", 3), kw.get("aa", 0), kw.get("renderer", 0))
+    px = np.zeros((h, w), np.uint32); sh = np.zeros((h, w), np.int32); tr = np.zeros((h, w), np.int32)
+    rays = C.c_uint64(0)
+    vp = C.c_void_p
+    rc = _hostcore().hc_render(vp(hs.flatten()), C.byref(cam), C.byref(prm), px.ctypes.data_as(vp), sh.ctypes.data_as(vp),
+                               tr.ctypes.data_as(vp), C.byref(rays), None, 4)
+    assert rc == 0
+    f = golden["frames"]
+    assert np.array_equal(px, f[name + "_pixels"])
+    assert np.array_equal(sh, f[name + "_shape"]) and np.array_equal(tr, f[name + "_tri"])
+    assert rays.value == int(f[name + "_rays"][0])
+
+
+def test_flattener_rejects_what_the_device_cannot_run(host_lib):
+    sd = scenes.SceneDesc()
+    m = sd.uniform_material(0xffffff, 0.5)
+    for _ in range(10):  # nest deeper than RTHIP_MAX_MAT_STACK on the right spine
+        m = sd.interpolated_material(sd.checker(1), sd.uniform_material(0x0, 0.5), m)
+    sd.sphere(m)
+    with pytest.raises(RuntimeError, match="nesting deeper"):  # right spine: the postfix stack grows to 11
+        host.HostScene(sd).flatten()
+    sd = scenes.SceneDesc()
+    m = sd.uniform_material(0xffffff, 0.5)
+    for _ in range(10):
+        m = sd.interpolated_material(sd.checker(1), m, sd.uniform_material(0x0, 0.5))
+    sd.sphere(m)
+    assert host.HostScene(sd).flatten()  # left spine: evaluation keeps the stack at 2
+
+
+def test_no_device_is_an_error_not_a_fallback(host_lib):
+    """without a GPU the product refuses to render (loud failure, no CPU path)"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    hs = host.HostScene(scenes.config(1)[0])
+    with pytest.raises(RuntimeError):
+        hs.render(32, 24)
+    with pytest.raises(device.RthipError):
+        device.Context(0)
+
+
+def test_scene_generators_are_deterministic():
+    g = scenes.PCG32(42)
+    seq = [g.next_u32() for _ in range(5)]
+    assert seq == [scenes.PCG32(42).next_u32()] + seq[1:]
+    a = scenes.PCG32(7).u32_array(70000)
+    g2 = scenes.PCG32(7)
+    assert a[:100].tolist() == [g2.next_u32() for _ in range(100)]
+    v, n = scenes.heightfield_mesh(cells=16, seed=3)
+    assert v.shape == (512, 9) and np.isfinite(v).all()
+    # counter-clockwise seen from +y (the reference culls back faces, Scene.cpp:430-441)
+    e0, e1 = v[:, 3:6] - v[:, 0:3], v[:, 6:9] - v[:, 3:6]
+    assert (np.cross(e0, e1)[:, 1] > 0).all()
+    x = np.linspace(-20, 20, 2001)
+    assert np.abs(scenes.det_sin(x) - np.sin(x)).max() < 1e-6  # a fixed polynomial: the generator's own definition

@@ -1,0 +1,135 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/*.npz from the GENUINE reference (oracle/_ref/libref.so, built by
+oracle/Makefile from /root/reference).  Container-only.  The fixtures hold expected OUTPUTS (and
+seeded probe inputs); scenes are regenerated from raytracing_amd.scenes on every machine.
+
+  python tools/make_golden.py            # frames + sparse 1080p + KATs + bunny kd dump (about a minute)
+  python tools/make_golden.py big        # sparse config-4 pixels (2M-triangle mesh; minutes, ~10 GB transient)
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import oracle  # noqa: E402
+from raytracing_amd import scenes  # noqa: E402
+
+G = scenes.GOLDEN_DIR
+R = oracle.load_ref()
+assert R.name == "reference"
+
+FRAME_CASES = {
+    # name: (scene factory, width, height, kwargs)
+    "cfg1": (lambda: scenes.config(1)[0], 160, 120, dict(max_recursion=1)),
+    "cfg2": (lambda: scenes.config(2)[0], 240, 135, dict(max_recursion=3)),
+    "cfg3": (lambda: scenes.config(3)[0], 240, 135, dict(max_recursion=3)),
+    "cfg3close": (lambda: scenes.config(3, cam_z=2.2)[0], 160, 90, dict(max_recursion=3)),
+    "demo3": (lambda: scenes.demo3_point_lights()[0], 160, 90, dict(max_recursion=3)),
+    "nested": (lambda: scenes.nested_transforms()[0], 160, 100, dict(max_recursion=4)),
+    "nested_ssaa": (lambda: scenes.nested_transforms()[0], 80, 50, dict(max_recursion=2, aa=1)),
+    "nested_dbgN": (lambda: scenes.nested_transforms()[0], 80, 50, dict(renderer=1)),
+    "nested_dbgC": (lambda: scenes.nested_transforms()[0], 80, 50, dict(renderer=2)),
+    "cfg2_dbgC": (lambda: scenes.config(2)[0], 120, 68, dict(renderer=2)),
+}
+SPARSE_CASES = {
+    "cfg2_1080p": (lambda: scenes.config(2)[0], 1920, 1080, dict(max_recursion=3), 4096, 11),
+    "cfg3_1080p": (lambda: scenes.config(3)[0], 1920, 1080, dict(max_recursion=3), 4096, 12),
+}
+
+
+def sparse_pixels(w, h, n, seed):
+    g = scenes.PCG32(seed)
+    xs = np.array([g.next_u32() % w for _ in range(n)], dtype=np.int32)
+    ys = np.array([g.next_u32() % h for _ in range(n)], dtype=np.int32)
+    return xs, ys
+
+
+def unit(g, n):
+    v = np.array([[g.next_u32() / 2**31 - 1.0 for _ in range(3)] for _ in range(n)])
+    return v / np.sqrt((v * v).sum(-1, keepdims=True))
+
+
+def main_small():
+    out = {}
+    for name, (mk, w, h, kw) in FRAME_CASES.items():
+        s = mk().build(R)
+        t = time.time()
+        r = s.render(w, h, ids=True, threads=8, **kw)
+        out[name + "_pixels"] = r["pixels"]
+        out[name + "_shape"] = r["shape"].astype(np.int16)
+        out[name + "_tri"] = r["tri"]
+        out[name + "_rays"] = np.array([r["rays"]], dtype=np.int64)
+        print(name, w, h, kw, "rays", r["rays"], "%.2fs" % (time.time() - t), flush=True)
+    np.savez_compressed(os.path.join(G, "frames.npz"), **out)
+
+    out = {}
+    for name, (mk, w, h, kw, n, seed) in SPARSE_CASES.items():
+        s = mk().build(R)
+        xs, ys = sparse_pixels(w, h, n, seed)
+        r = s.render(w, h, ids=True, sub=(xs, ys), **kw)
+        out[name + "_x"], out[name + "_y"] = xs.astype(np.int16), ys.astype(np.int16)
+        out[name + "_pixels"], out[name + "_shape"], out[name + "_tri"] = r["pixels"], r["shape"].astype(np.int16), r["tri"]
+        print(name, "sparse", n, flush=True)
+    np.savez_compressed(os.path.join(G, "sparse.npz"), **out)
+
+    # known-answer vectors on two scenes
+    out = {}
+    for name, mk in (("nested", lambda: scenes.nested_transforms()[0]), ("cfg2", lambda: scenes.config(2)[0]),
+                     ("cfg3", lambda: scenes.config(3)[0])):
+        sd = mk()
+        s = sd.build(R)
+        g = scenes.PCG32(1000 + len(name))
+        n = 1536
+        cam = np.array(sd.camera_pos)
+        o = cam + np.array([[g.next_u32() / 2**32 - 0.5 for _ in range(3)] for _ in range(n)]) * 2.0
+        d = unit(g, n)
+        d[: n // 2, 1] = -np.abs(d[: n // 2, 1])  # half of them look down towards the geometry
+        d[: n // 4] = (np.array([0, 0, -6.0]) - o[: n // 4]) + d[: n // 4] * 1.5
+        d = d / np.sqrt((d * d).sum(-1, keepdims=True))
+        c = s.cast_rays(o, d)
+        out[name + "_ray_o"], out[name + "_ray_d"] = o, d
+        for k in ("hit", "point", "local", "normal", "shape", "tri"):
+            out[name + "_cast_" + k] = c[k]
+        out[name + "_raycast"] = s.raycast(o, d, 3)
+        out[name + "_background"] = s.background_eval(d)
+        p = np.array([[(g.next_u32() / 2**32 - 0.5) * 40 for _ in range(3)] for _ in range(n)])
+        p[:64] = np.round(p[:64])            # lattice / cell-boundary points
+        p[64:96] *= 1e-3
+        out[name + "_points"] = p
+        for ni, info in sd.noise_info.items():
+            out[f"{name}_noise{ni}"] = s.noise_sample(ni, p)
+        for mi in range(sd._n["mat"]):
+            col, ab = s.material_eval(mi, p)
+            out[f"{name}_mat{mi}_color"], out[f"{name}_mat{mi}_abs"] = col, ab
+        for node in range(1, sd._n["node"]):
+            out[f"{name}_node{node}_matrices"] = s.node_matrices(node)
+        print("kat", name, flush=True)
+    np.savez_compressed(os.path.join(G, "kat.npz"), **out)
+
+    sd = scenes.config(3)[0]
+    s = sd.build(R)
+    kd = s.kd_dump(2)
+    np.savez_compressed(os.path.join(G, "bunny_kd.npz"), depth=kd["depth"].astype(np.int8), ntris=kd["ntris"].astype(np.int16),
+                        split=kd["split"], bounds=kd["bounds"], refs=kd["refs"].astype(np.int16))
+    print("bunny kd", len(kd["depth"]), len(kd["refs"]), flush=True)
+
+
+def main_big():
+    sd, kw = scenes.config(4)
+    t = time.time()
+    s = sd.build(R)
+    w, h = kw["width"], kw["height"]
+    xs, ys = sparse_pixels(w, h, 2048, 14)
+    r = s.render(w, h, ids=True, sub=(xs, ys), max_recursion=kw["max_recursion"])
+    np.savez_compressed(os.path.join(G, "sparse_cfg4.npz"), x=xs.astype(np.int16), y=ys.astype(np.int16), pixels=r["pixels"],
+                        shape=r["shape"].astype(np.int16), tri=r["tri"])
+    print("cfg4 sparse done in %.1fs" % (time.time() - t), flush=True)
+
+
+if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "big":
+        main_big()
+    else:
+        main_small()
