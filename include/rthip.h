@@ -83,12 +83,41 @@ typedef struct {
     double d00, d01, d11, inv_den;
 } rthip_tri;
 
+/* Device-oriented bounding-volume hierarchy over the SAME triangles (no reference counterpart: the
+ * reference only has the kd-tree above).  Mesh::Intersect returns the strictly closest triangle hit of
+ * the whole mesh (argmin over triangles, Scene.cpp:469-493), so any conservative culling structure
+ * yields the same result; this one is binary, 64 bytes per node, child boxes stored in the parent in
+ * fp32 rounded OUTWARD.  Child word: bit 31 set = leaf, bits 28..30 = triangle count - 1, bits 0..27 =
+ * first triangle in bvh_tris (mesh-relative); else index of the child node (mesh-relative).
+ * An absent child has lo = +inf, hi = -inf. */
+typedef struct {
+    float lo0[3], hi0[3];
+    float lo1[3], hi1[3];
+    uint32_t child0, child1;
+    uint32_t pad[2];
+} rthip_bvhnode;
+#define RTHIP_BVH_LEAF 0x80000000u
+#define RTHIP_BVH_COUNT_SHIFT 28
+#define RTHIP_BVH_FIRST_MASK 0x0fffffffu
+#define RTHIP_BVH_MAX_DEPTH 62
+
 typedef struct {
     uint32_t node_base, node_count;   /* into kd_nodes / kd_bounds */
     uint32_t ref_base, ref_count;     /* into kd_refs (values are mesh-relative triangle indices) */
     uint32_t tri_base, tri_count;     /* into tris / tri_normals */
     int32_t normal_mode;              /* 0 Face, 1 Vertex (Scene.h:18) */
-    uint32_t max_depth;               /* deepest node, sizes the traversal stack */
+    uint32_t max_depth;               /* deepest kd node, sizes the traversal stack */
+    uint32_t bvh_node_base, bvh_node_count;   /* into bvh_nodes */
+    uint32_t bvh_tri_base;            /* into bvh_tris / bvh_tri_index (tri_count entries, leaf order) */
+    uint32_t bvh_depth;               /* deepest BVH node */
+    float abs_max;                    /* max |coordinate| of the mesh's vertices (slab-test slack) */
+    uint32_t pad;
+    /* kd_planes[plane_base[a] .. +plane_count[a]) = sorted unique plane coordinates of the kd-tree's
+     * boxes on axis a (root bounds + split values).  A ray with direction component a exactly 0 whose
+     * origin coordinate a equals one of them makes the reference's slab test produce 0/0 = NaN
+     * (Common.cpp:349-356) and take decisions no geometric structure reproduces: such rays are routed
+     * through the kd-tree even when accel = 0. */
+    uint32_t plane_base[3], plane_count[3];
 } rthip_mesh;
 
 /* Material trees in postfix order: UNIFORM pushes (color, absorptance); INTERP pops b then a and
@@ -143,8 +172,12 @@ typedef struct {
     const rthip_kdnode *kd_nodes;       uint64_t n_kd_nodes;
     const double *kd_bounds;            /* n_kd_nodes * 6: Min xyz, Max xyz (KDTreeTriangle::Bounds) */
     const uint32_t *kd_refs;            uint64_t n_kd_refs;
+    const double *kd_planes;            uint64_t n_kd_planes;
     const rthip_tri *tris;              uint64_t n_tris;
     const double *tri_normals;          /* n_tris * 9: Triangle::Normals */
+    const rthip_bvhnode *bvh_nodes;     uint64_t n_bvh_nodes;
+    const rthip_tri *bvh_tris;          /* n_tris records in BVH leaf order */
+    const uint32_t *bvh_tri_index;      /* n_tris: leaf-order position -> mesh-relative triangle index */
     const rthip_matop *materials;       uint32_t n_materials;
     const rthip_noise *noises;          uint32_t n_noises;
     const uint8_t *perlin_tables;       uint32_t n_perlin_tables;   /* n * 256 bytes */
@@ -176,6 +209,9 @@ typedef struct {
      * 1 = d_pixels is this part's tile-compact buffer: rthip_part_pixels() uint32, tile after tile in
      * this part's tile order, 8x8 sub-blocks inside a tile (what the multi-GPU gather ships) */
     int32_t layout;
+    /* mesh acceleration structure: 0 = BVH (default), 1 = the reference's kd-tree (same results;
+     * kept for parity tests and as the literal flattening of KDTreeTriangle) */
+    int32_t accel;
 } rthip_params;
 
 typedef struct {

@@ -39,8 +39,13 @@ struct SceneView {
     const rthip_kdnode *kd_nodes;
     const double *kd_bounds;
     const uint32_t *kd_refs;
+    const double *kd_planes;
     const rthip_tri *tris;
     const double *tri_normals;
+    const rthip_bvhnode *bvh_nodes;
+    const rthip_tri *bvh_tris;
+    const uint32_t *bvh_tri_index;
+    int32_t accel;  // 0 = BVH, 1 = reference kd-tree
     const rthip_matop *materials;
     const rthip_noise *noises;
     const uint8_t *perlin_tables;
@@ -456,6 +461,121 @@ RT_HD void mesh_closest(const SceneView &sv, const rthip_mesh &m, V3 o, V3 d, Kd
     }
 }
 
+// T4 through the device-oriented BVH: same result as mesh_closest (argmin over the mesh's triangles
+// of the reference's d = |O-P|^2 with the reference's triangle test), different culling structure.
+// Box tests are fp32 and CONSERVATIVE — child boxes are stored rounded outward, every slab interval is
+// widened by `pad`*|1/d| (pad covers the fp32 rounding of the origin and of the plane differences), so
+// a box that could contain a closer-or-equal hit is never skipped; they take no part in the result's
+// arithmetic.  Near child first; the far child is pushed on the LDS stack.
+RT_HD void bvh_slab(const float *lo, const float *hi, float ox, float oy, float oz, float ix, float iy, float iz,
+                    float sx, float sy, float sz, float tmax, float &tn, bool &hit) {
+    float ax = (lo[0] - ox) * ix, bx = (hi[0] - ox) * ix;
+    float ay = (lo[1] - oy) * iy, by = (hi[1] - oy) * iy;
+    float az = (lo[2] - oz) * iz, bz = (hi[2] - oz) * iz;
+    float nx = fminf(ax, bx) - sx, fx = fmaxf(ax, bx) + sx;
+    float ny = fminf(ay, by) - sy, fy = fmaxf(ay, by) + sy;
+    float nz = fminf(az, bz) - sz, fz = fmaxf(az, bz) + sz;
+    tn = fmaxf(fmaxf(nx, ny), fmaxf(nz, 0.0f));
+    float tf = fminf(fminf(fx, fy), fminf(fz, tmax));
+    hit = tn <= tf;
+}
+RT_HD float bvh_inv(double d) {
+    float f = (float)d;
+    float r = 1.0f / f;
+    const float big = 1e30f;  // keeps (plane - origin) * inv and pad * |inv| finite: no inf - inf
+    if (!(fabsf(r) < big)) r = (f < 0.0f || (f == 0.0f && d < 0.0)) ? -big : big;
+    return r;
+}
+RT_HD void bvh_leaf(const rthip_tri *tris, const uint32_t *index, uint32_t word, V3 o, V3 d, TriBest &best, float &tmax,
+                    KdCounters *cnt) {
+    uint32_t first = word & RTHIP_BVH_FIRST_MASK, count = ((word >> RTHIP_BVH_COUNT_SHIFT) & 7u) + 1u;
+    if (cnt) {
+        cnt->leaves++;
+        cnt->tris += count;
+    }
+    for (uint32_t i = 0; i < count; i++) {
+        uint32_t ti = index[first + i];
+        tri_test(tris[first + i], o, d, ti, ti, best);  // ties: lower triangle index (== earlier in the reference walk)
+    }
+    if (best.hit) {
+        // upper bound of the hit parameter: sqrt(d) rounded up, two float ulps of margin
+        float t = (float)sqrt(best.d);
+        tmax = t + t * 2.4e-7f + 1e-37f;
+    }
+}
+RT_HD void mesh_closest_bvh(const SceneView &sv, const rthip_mesh &m, V3 o, V3 d, KdStack &st, TriBest &best,
+                            KdCounters *cnt) {
+    best.hit = false;
+    best.d = DBL_MAX;
+    best.tri = 0xffffffffu;
+    best.ref = 0xffffffffu;
+    if (m.bvh_node_count == 0) return;
+    const rthip_bvhnode *nodes = sv.bvh_nodes + m.bvh_node_base;
+    const rthip_tri *tris = sv.bvh_tris + m.bvh_tri_base;
+    const uint32_t *index = sv.bvh_tri_index + m.bvh_tri_base;
+    const float ox = (float)o.x, oy = (float)o.y, oz = (float)o.z;
+    const float ix = bvh_inv(d.x), iy = bvh_inv(d.y), iz = bvh_inv(d.z);
+    const float pad = 4.8e-7f * (fmaxf(fmaxf(fabsf(ox), fabsf(oy)), fabsf(oz)) + m.abs_max) + 1e-30f;  // 2^-21 * magnitude
+    const float sx = pad * fabsf(ix), sy = pad * fabsf(iy), sz = pad * fabsf(iz);
+    float tmax = 3.0e38f;
+    st.clear();
+    uint32_t cur = 0;
+    for (;;) {
+        const rthip_bvhnode &nd = nodes[cur];
+        if (cnt) cnt->nodes++;
+        float t0, t1;
+        bool h0, h1;
+        bvh_slab(nd.lo0, nd.hi0, ox, oy, oz, ix, iy, iz, sx, sy, sz, tmax, t0, h0);
+        bvh_slab(nd.lo1, nd.hi1, ox, oy, oz, ix, iy, iz, sx, sy, sz, tmax, t1, h1);
+        uint32_t c0 = nd.child0, c1 = nd.child1;
+        // leaves are tested as soon as they are reached (their boxes were just tested)
+        if (h0 && (c0 & RTHIP_BVH_LEAF)) {
+            bvh_leaf(tris, index, c0, o, d, best, tmax, cnt);
+            h0 = false;
+            if (h1 && t1 > tmax) h1 = false;
+        }
+        if (h1 && (c1 & RTHIP_BVH_LEAF)) {
+            bvh_leaf(tris, index, c1, o, d, best, tmax, cnt);
+            h1 = false;
+            if (h0 && t0 > tmax) h0 = false;
+        }
+        if (h0 && h1) {
+            bool first0 = t0 <= t1;
+            st.push(first0 ? c1 : c0);
+            cur = first0 ? c0 : c1;
+            continue;
+        }
+        if (h0) { cur = c0; continue; }
+        if (h1) { cur = c1; continue; }
+        if (st.empty()) break;
+        if (cnt) cnt->pops++;
+        cur = st.pop();
+    }
+}
+
+// true iff `v` is exactly one of the mesh's kd box-plane coordinates on `axis` (binary search)
+RT_HD bool kd_on_plane(const SceneView &sv, const rthip_mesh &m, uint32_t axis, double v) {
+    const double *p = sv.kd_planes + m.plane_base[axis];
+    uint32_t lo = 0, hi = m.plane_count[axis];
+    while (lo < hi) {
+        uint32_t mid = (lo + hi) >> 1;
+        double x = p[mid];
+        if (x == v) return true;
+        if (x < v) lo = mid + 1; else hi = mid;
+    }
+    return false;
+}
+// The reference's slab test divides by the direction (Common.cpp:349-354): a component that is exactly
+// 0 with the origin exactly on a box plane gives 0/0 = NaN, which fmin/fmax drop, and the walk then
+// accepts/rejects boxes in a way only the reference's own tree reproduces.
+RT_HD bool kd_degenerate_ray(const SceneView &sv, const rthip_mesh &m, V3 o, V3 d) {
+    bool r = false;
+    if (d.x == 0.0) r = r || kd_on_plane(sv, m, 0, o.x);
+    if (d.y == 0.0) r = r || kd_on_plane(sv, m, 1, o.y);
+    if (d.z == 0.0) r = r || kd_on_plane(sv, m, 2, o.z);
+    return r;
+}
+
 // ----------------------------------------------------------------------------- scene query (S1)
 struct Hit {
     int32_t shape;  // pre-order ordinal into sv.shapes, -1 = miss
@@ -488,7 +608,10 @@ RT_HD Hit cast_ray(const SceneView &sv, V3 o, V3 d, KdStack &st, bool any_hit, K
         } else if (sh.type == RTHIP_SHAPE_PLANE) {
             hit = plane_intersect(mk(sh.plane_n[0], sh.plane_n[1], sh.plane_n[2]), lo, ld, p);
         } else {
-            mesh_closest(sv, sv.meshes[sh.mesh], lo, ld, st, tb, cnt);
+            if (sv.accel == 0 && !kd_degenerate_ray(sv, sv.meshes[sh.mesh], lo, ld))
+                mesh_closest_bvh(sv, sv.meshes[sh.mesh], lo, ld, st, tb, cnt);
+            else
+                mesh_closest(sv, sv.meshes[sh.mesh], lo, ld, st, tb, cnt);
             hit = tb.hit;
             p = tb.point;
             tri = (int32_t)tb.tri;

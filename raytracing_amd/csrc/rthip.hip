@@ -345,6 +345,8 @@ struct rthip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    DevBuf bvh_nodes, bvh_tris, bvh_index, kd_planes;
+    uint32_t stack_cap_kd = 1, stack_cap_bvh = 1;
     DevBuf shapes, meshes, kd_nodes, kd_bounds, kd_refs, tris, tri_normals, materials, noises, perlin, worley, lights;
     SceneView sv;
     bool has_scene = false;
@@ -400,7 +402,7 @@ int rthip_destroy(rthip_ctx *c) {
     (void)hipStreamSynchronize(c->stream);
     DevBuf *all[] = {&c->shapes, &c->meshes, &c->kd_nodes, &c->kd_bounds, &c->kd_refs, &c->tris, &c->tri_normals,
                      &c->materials, &c->noises, &c->perlin, &c->worley, &c->lights, &c->rec, &c->parent, &c->rays,
-                     &c->counts, &c->stats, &c->ids, &c->pixels_tmp, &c->ids_out};
+                     &c->counts, &c->stats, &c->ids, &c->pixels_tmp, &c->ids_out, &c->bvh_nodes, &c->bvh_tris, &c->bvh_index, &c->kd_planes};
     for (DevBuf *b : all) b->release();
     for (DevBuf &b : c->probe) b.release();
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
@@ -430,17 +432,19 @@ int rthip_get_stats(rthip_ctx *c, rthip_stats *out) {
 }
 
 // ---------------------------------------------------------------------------- scene upload
-static int validate_scene(const rthip_scene_desc *s, uint32_t *max_depth) {
+static int validate_scene(const rthip_scene_desc *s, uint32_t *max_depth, uint32_t *max_bvh_depth) {
 #define BAD(...) return fail(RTHIP_E_INVALID, "rthip_upload_scene: " __VA_ARGS__)
     if (s->n_shapes && !s->shapes) BAD("shapes is null");
     if (s->n_lights && !s->lights) BAD("lights is null");
     if (s->n_materials && !s->materials) BAD("materials is null");
     if (s->n_noises && !s->noises) BAD("noises is null");
     if (s->n_meshes && (!s->meshes || !s->kd_nodes || !s->kd_bounds || !s->tris || !s->tri_normals)) BAD("mesh arrays are null");
+    if (s->n_meshes && s->n_tris && (!s->bvh_nodes || !s->bvh_tris || !s->bvh_tri_index)) BAD("bvh arrays are null");
     if (s->n_kd_refs && !s->kd_refs) BAD("kd_refs is null");
     if (s->n_perlin_tables && !s->perlin_tables) BAD("perlin_tables is null");
     if (s->n_worley_points && !s->worley_points) BAD("worley_points is null");
     *max_depth = 0;
+    *max_bvh_depth = 0;
     for (uint32_t i = 0; i < s->n_noises; i++) {
         const rthip_noise &n = s->noises[i];
         if (n.type < RTHIP_NOISE_CHECKER || n.type > RTHIP_NOISE_MARBLE) BAD("noise %u: bad type %d", i, n.type);
@@ -488,6 +492,28 @@ static int validate_scene(const rthip_scene_desc *s, uint32_t *max_depth) {
         }
         for (uint32_t k = 0; k < m.ref_count; k++)
             if (s->kd_refs[m.ref_base + k] >= m.tri_count) BAD("mesh %u: ref %u -> triangle out of range", i, k);
+        for (int a = 0; a < 3; a++)
+            if ((uint64_t)m.plane_base[a] + m.plane_count[a] > s->n_kd_planes || (m.plane_count[a] && !s->kd_planes)) BAD("mesh %u: kd planes out of range", i);
+        if ((uint64_t)m.bvh_node_base + m.bvh_node_count > s->n_bvh_nodes) BAD("mesh %u: bvh nodes out of range", i);
+        if (m.bvh_depth > RTHIP_BVH_MAX_DEPTH) BAD("mesh %u: bvh_depth %u", i, m.bvh_depth);
+        if (m.bvh_node_count && (uint64_t)m.bvh_tri_base + m.tri_count > s->n_tris) BAD("mesh %u: bvh triangles out of range", i);
+        if (m.bvh_depth > *max_bvh_depth) *max_bvh_depth = m.bvh_depth;
+        if (!(m.abs_max >= 0.0f)) BAD("mesh %u: abs_max", i);
+        for (uint32_t k = 0; k < m.bvh_node_count; k++) {
+            const rthip_bvhnode &nd = s->bvh_nodes[m.bvh_node_base + k];
+            const uint32_t ch[2] = {nd.child0, nd.child1};
+            for (int c = 0; c < 2; c++) {
+                if (ch[c] & RTHIP_BVH_LEAF) {
+                    bool absent = c == 1 ? !(nd.lo1[0] <= nd.hi1[0]) : !(nd.lo0[0] <= nd.hi0[0]);
+                    uint64_t first = ch[c] & RTHIP_BVH_FIRST_MASK, cnt = ((ch[c] >> RTHIP_BVH_COUNT_SHIFT) & 7u) + 1u;
+                    if (!absent && first + cnt > m.tri_count) BAD("mesh %u bvh node %u: leaf out of range", i, k);
+                } else if (ch[c] >= m.bvh_node_count || ch[c] <= k) {
+                    BAD("mesh %u bvh node %u: child out of range", i, k);
+                }
+            }
+        }
+        for (uint32_t k = 0; k < (m.bvh_node_count ? m.tri_count : 0); k++)
+            if (s->bvh_tri_index[m.bvh_tri_base + k] >= m.tri_count) BAD("mesh %u: bvh triangle index out of range", i);
     }
     for (uint32_t i = 0; i < s->n_shapes; i++) {
         const rthip_shape &sh = s->shapes[i];
@@ -515,8 +541,8 @@ static int upload(rthip_ctx *c, DevBuf &b, const void *src, size_t bytes) {
 
 int rthip_upload_scene(rthip_ctx *c, const rthip_scene_desc *s) {
     if (!c || !s) return fail(RTHIP_E_INVALID, "rthip_upload_scene: null argument");
-    uint32_t max_depth = 0;
-    int rc = validate_scene(s, &max_depth);
+    uint32_t max_depth = 0, max_bvh_depth = 0;
+    int rc = validate_scene(s, &max_depth, &max_bvh_depth);
     if (rc) return rc;
     if (set_device(c)) return RTHIP_E_HIP;
     c->has_scene = false;
@@ -528,6 +554,10 @@ int rthip_upload_scene(rthip_ctx *c, const rthip_scene_desc *s) {
     if ((rc = upload(c, c->kd_refs, s->kd_refs, sizeof(uint32_t) * s->n_kd_refs))) return rc;
     if ((rc = upload(c, c->tris, s->tris, sizeof(rthip_tri) * s->n_tris))) return rc;
     if ((rc = upload(c, c->tri_normals, s->tri_normals, sizeof(double) * 9 * s->n_tris))) return rc;
+    if ((rc = upload(c, c->kd_planes, s->kd_planes, sizeof(double) * s->n_kd_planes))) return rc;
+    if ((rc = upload(c, c->bvh_nodes, s->bvh_nodes, sizeof(rthip_bvhnode) * s->n_bvh_nodes))) return rc;
+    if ((rc = upload(c, c->bvh_tris, s->bvh_tris, s->n_bvh_nodes ? sizeof(rthip_tri) * s->n_tris : 0))) return rc;
+    if ((rc = upload(c, c->bvh_index, s->bvh_tri_index, s->n_bvh_nodes ? sizeof(uint32_t) * s->n_tris : 0))) return rc;
     if ((rc = upload(c, c->materials, s->materials, sizeof(rthip_matop) * s->n_materials))) return rc;
     if ((rc = upload(c, c->noises, s->noises, sizeof(rthip_noise) * s->n_noises))) return rc;
     if ((rc = upload(c, c->perlin, s->perlin_tables, (size_t)256 * s->n_perlin_tables))) return rc;
@@ -543,6 +573,11 @@ int rthip_upload_scene(rthip_ctx *c, const rthip_scene_desc *s) {
     v.kd_refs = (const uint32_t *)c->kd_refs.p;
     v.tris = (const rthip_tri *)c->tris.p;
     v.tri_normals = (const double *)c->tri_normals.p;
+    v.kd_planes = (const double *)c->kd_planes.p;
+    v.bvh_nodes = (const rthip_bvhnode *)c->bvh_nodes.p;
+    v.bvh_tris = (const rthip_tri *)c->bvh_tris.p;
+    v.bvh_tri_index = (const uint32_t *)c->bvh_index.p;
+    v.accel = 0;
     v.materials = (const rthip_matop *)c->materials.p;
     v.noises = (const rthip_noise *)c->noises.p;
     v.perlin_tables = (const uint8_t *)c->perlin.p;
@@ -550,7 +585,10 @@ int rthip_upload_scene(rthip_ctx *c, const rthip_scene_desc *s) {
     v.lights = (const rthip_light *)c->lights.p;
     v.n_lights = s->n_lights;
     v.bg = s->background;
-    c->stack_cap = max_depth + 2;
+    c->stack_cap_kd = max_depth + 2;
+    c->stack_cap_bvh = max_bvh_depth + 2;
+    c->stack_cap_bvh = (max_depth > max_bvh_depth ? max_depth : max_bvh_depth) + 2;  // degenerate rays walk the kd-tree
+    c->stack_cap = c->stack_cap_bvh;
     c->has_scene = true;
     return 0;
 }
@@ -568,6 +606,7 @@ static int check_params(const rthip_camera *cam, const rthip_params *p) {
     uint32_t tw = p->tile_w ? p->tile_w : 32, th = p->tile_h ? p->tile_h : 8;
     if (tw % 8 || th % 8 || tw > 1024 || th > 1024) return fail(RTHIP_E_INVALID, "rthip_render: tile %ux%u must be multiples of 8", tw, th);
     if (p->layout != 0 && p->layout != 1) return fail(RTHIP_E_INVALID, "rthip_render: layout %d", p->layout);
+    if (p->accel != 0 && p->accel != 1) return fail(RTHIP_E_INVALID, "rthip_render: accel %d", p->accel);
     return 0;
 }
 
@@ -623,6 +662,8 @@ static int render_frame(rthip_ctx *c, const rthip_camera *cam, const rthip_param
     w.id_tri = w.id_shape ? w.id_shape + (size_t)tiles_per_chunk * per_tile : nullptr;
     w.N = (uint32_t)N;
 
+    c->sv.accel = p->accel;
+    c->stack_cap = p->accel ? c->stack_cap_kd : c->stack_cap_bvh;
     const size_t lds_bytes = (size_t)c->stack_cap * kBlock * sizeof(uint32_t);
     if (lds_bytes > 160 * 1024) return fail(RTHIP_E_UNSUPPORTED, "kd stack of %u entries does not fit LDS", c->stack_cap);
     if (lds_bytes > 64 * 1024)

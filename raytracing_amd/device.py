@@ -29,7 +29,7 @@ class Camera(C.Structure):
 class Params(C.Structure):
     _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("max_recursion", C.c_uint32),
                 ("aa_mode", C.c_int32), ("renderer", C.c_int32), ("part_index", C.c_uint32),
-                ("part_count", C.c_uint32), ("tile_w", C.c_uint32), ("tile_h", C.c_uint32), ("layout", C.c_int32)]
+                ("part_count", C.c_uint32), ("tile_w", C.c_uint32), ("tile_h", C.c_uint32), ("layout", C.c_int32), ("accel", C.c_int32)]
 
 
 class Stats(C.Structure):
@@ -90,8 +90,8 @@ def _dp(a):
     return None if a is None else a.ctypes.data_as(c_dp)
 
 
-def make_params(width, height, max_recursion=3, aa=0, renderer=0, part_index=0, part_count=1, tile_w=0, tile_h=0, layout=0):
-    return Params(width, height, max_recursion, aa, renderer, part_index, part_count, tile_w, tile_h, layout)
+def make_params(width, height, max_recursion=3, aa=0, renderer=0, part_index=0, part_count=1, tile_w=0, tile_h=0, layout=0, accel=0):
+    return Params(width, height, max_recursion, aa, renderer, part_index, part_count, tile_w, tile_h, layout, accel)
 
 
 def part_pixels(params):

@@ -25,6 +25,7 @@ def load_host():
         L.rehost_flatten.argtypes = [C.c_void_p]; L.rehost_flatten.restype = C.c_void_p
         L.rehost_camera.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.POINTER(device.Camera)]
         L.rehost_set_device.argtypes = [C.c_void_p, C.c_int]; L.rehost_set_device.restype = None
+        L.rehost_set_accel.argtypes = [C.c_void_p, C.c_int]; L.rehost_set_accel.restype = None
         L.rehost_shape_count.argtypes = [C.c_void_p]
         L.rehost_shape_ordinal.argtypes = [C.c_void_p, C.c_int]
         L.rehost_last_stats.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
@@ -48,6 +49,9 @@ class HostScene:
         self.L = self.sb.lib
         self.h = self.built.h
         self.L.rehost_set_device(self.h, device_index)
+
+    def set_accel(self, use_reference_kd):
+        self.L.rehost_set_accel(self.h, int(bool(use_reference_kd)))
 
     def flatten(self):
         """`const rthip_scene_desc*` of the compiled scene (valid until the scene is freed)."""

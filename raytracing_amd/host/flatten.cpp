@@ -4,6 +4,7 @@
 // tables, lights and background.
 #include "flatten.hpp"
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <map>
@@ -149,6 +150,42 @@ struct Flattener {
         }
         out.kd_bounds.insert(out.kd_bounds.end(), kd.bounds.begin(), kd.bounds.end());
         out.kd_refs.insert(out.kd_refs.end(), kd.refs.begin(), kd.refs.end());
+        for (unsigned a = 0; a < 3; a++) {  // plane coordinates of every kd box on axis a
+            std::vector<double> planes = {kd.bounds[a], kd.bounds[3 + a]};
+            for (const auto &n : kd.nodes)
+                if (!(n.info & RTHIP_KD_LEAF) && (n.info & RTHIP_KD_AXIS_MASK) == a) planes.push_back(n.split);
+            std::sort(planes.begin(), planes.end());
+            planes.erase(std::unique(planes.begin(), planes.end()), planes.end());
+            m.plane_base[a] = (uint32_t)out.kd_planes.size();
+            m.plane_count[a] = (uint32_t)planes.size();
+            out.kd_planes.insert(out.kd_planes.end(), planes.begin(), planes.end());
+        }
+        const BvhFlat &bvh = mesh->GetBvh();
+        if (bvh.depth > RTHIP_BVH_MAX_DEPTH) return Unsupported("BVH deeper than the device stack");
+        if (bvh.order.size() != tris.size() || tris.size() > RTHIP_BVH_FIRST_MASK) return Unsupported("mesh too large for the BVH leaf encoding");
+        m.bvh_node_base = (uint32_t)out.bvh_nodes.size();
+        m.bvh_node_count = (uint32_t)bvh.nodes.size();
+        m.bvh_tri_base = (uint32_t)out.bvh_tris.size();
+        m.bvh_depth = bvh.depth;
+        m.abs_max = bvh.abs_max;
+        for (const auto &n : bvh.nodes) {
+            rthip_bvhnode d;
+            std::memcpy(&d, &n, sizeof d);
+            out.bvh_nodes.push_back(d);
+        }
+        auto pack = [](const Triangle &t) {
+            rthip_tri r;
+            Put(r.v0, t.Vertices[0]);
+            Put(r.face_normal, t.FaceNormal);
+            Put(r.e0, t.Edges[0]);
+            Put(r.e1, t.Edges[1]);
+            r.d00 = t.D00(); r.d01 = t.D01(); r.d11 = t.D11(); r.inv_den = t.InvDen();
+            return r;
+        };
+        for (uint32_t ti : bvh.order) {
+            out.bvh_tris.push_back(pack(tris[ti]));
+            out.bvh_tri_index.push_back(ti);
+        }
         for (const Triangle &t : tris) {
             rthip_tri r;
             Put(r.v0, t.Vertices[0]);
@@ -257,8 +294,12 @@ struct Flattener {
         d.kd_nodes = out.kd_nodes.data();           d.n_kd_nodes = out.kd_nodes.size();
         d.kd_bounds = out.kd_bounds.data();
         d.kd_refs = out.kd_refs.data();             d.n_kd_refs = out.kd_refs.size();
+        d.kd_planes = out.kd_planes.data();         d.n_kd_planes = out.kd_planes.size();
         d.tris = out.tris.data();                   d.n_tris = out.tris.size();
         d.tri_normals = out.tri_normals.data();
+        d.bvh_nodes = out.bvh_nodes.data();         d.n_bvh_nodes = out.bvh_nodes.size();
+        d.bvh_tris = out.bvh_tris.data();
+        d.bvh_tri_index = out.bvh_tri_index.data();
         d.materials = out.materials.data();         d.n_materials = (uint32_t)out.materials.size();
         d.noises = out.noises.data();               d.n_noises = (uint32_t)out.noises.size();
         d.perlin_tables = out.perlin_tables.data(); d.n_perlin_tables = (uint32_t)(out.perlin_tables.size() / 256);

@@ -15,8 +15,12 @@ struct FlatScene {
     std::vector<rthip_kdnode> kd_nodes;
     std::vector<double> kd_bounds;
     std::vector<uint32_t> kd_refs;
+    std::vector<double> kd_planes;
     std::vector<rthip_tri> tris;
     std::vector<double> tri_normals;
+    std::vector<rthip_bvhnode> bvh_nodes;
+    std::vector<rthip_tri> bvh_tris;
+    std::vector<uint32_t> bvh_tri_index;
     std::vector<rthip_matop> materials;
     std::vector<rthip_noise> noises;
     std::vector<uint8_t> perlin_tables;

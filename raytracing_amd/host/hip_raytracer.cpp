@@ -119,6 +119,7 @@ void HipRaytracer::RenderThread(Scene *scene, std::promise<RenderStatus> p) {
             prm.tile_w = TileWidth;
             prm.tile_h = TileHeight;
             prm.layout = 0;
+            prm.accel = UseReferenceKdTree ? 1 : 0;
             rc = rthip_render(m_Ctx, &cam, &prm, m_Pixels, nullptr, nullptr);
             if (rc == RTHIP_E_INTERRUPTED) {
                 m_Interrupted = true;

@@ -74,6 +74,7 @@ public:
     int Device = 0;                         // HIP device ordinal of this process
     unsigned int PartIndex = 0, PartCount = 1;  // interleaved-tile share rendered by this process
     unsigned int TileWidth = 32, TileHeight = 8;
+    bool UseReferenceKdTree = false;        // traverse the reference's kd-tree instead of the BVH (same image)
 
     HipRaytracer(unsigned int viewWidth, unsigned int viewHeight, real fovY = PI / 4.0f);
     ~HipRaytracer() override;

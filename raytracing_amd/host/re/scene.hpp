@@ -209,6 +209,15 @@ struct KdTreeFlat {
     uint32_t max_depth = 0;
 };
 
+// Device-oriented BVH over the same triangles (no reference counterpart; see include/rthip.h).
+struct BvhFlat {
+    struct Node { float lo0[3], hi0[3], lo1[3], hi1[3]; uint32_t child0, child1, pad[2]; };
+    std::vector<Node> nodes;
+    std::vector<uint32_t> order;  // leaf-order position -> triangle index
+    uint32_t depth = 0;
+    float abs_max = 0.f;
+};
+
 class Mesh : public Shape {
 public:
     explicit Mesh(SceneNode *owner) : Shape(owner) {}
@@ -218,10 +227,12 @@ public:
     void Invalidate() { m_Invalidated = true; }
     const std::vector<Triangle> &GetTriangles() const { return m_Triangles; }  // additive
     const KdTreeFlat &GetKdTree() const { return m_KdTree; }                    // additive
+    const BvhFlat &GetBvh() const { return m_Bvh; }                             // additive
     const BoundingBox &GetBounds() const { return m_BoundingBox; }              // additive
 private:
     bool m_Invalidated = true;
     KdTreeFlat m_KdTree;
+    BvhFlat m_Bvh;
     std::vector<Triangle> m_Triangles;
     BoundingBox m_BoundingBox;
 };

@@ -27,6 +27,7 @@ struct sb_scene {
     rthip_ctx *ctx = nullptr;         // probe context (lazy)
     bool uploaded = false;
     int device = 0;
+    int use_kd = 0;
     HipRenderStats last_stats;
     ~sb_scene() { if (ctx) rthip_destroy(ctx); }
 };
@@ -207,6 +208,7 @@ int rehost_camera(sb_scene *s, int width, int height, double fovy, rthip_camera 
     return 0;
 }
 void rehost_set_device(sb_scene *s, int device) { s->device = device; }
+void rehost_set_accel(sb_scene *s, int use_reference_kd) { s->use_kd = use_reference_kd; }
 int rehost_shape_count(sb_scene *s) { return ensure_flat(s) ? -1 : (int)s->flat->shapes.size(); }
 // shape ordinal of a node id (or -1)
 int rehost_shape_ordinal(sb_scene *s, int node) {
@@ -240,6 +242,7 @@ int sb_render(sb_scene *s, const sb_render_params *p, uint32_t *pixels, int32_t 
         rt->MaxRecursion = p->max_recursion;
         rt->NumThreads = p->num_threads;
         rt->Device = s->device;
+        rt->UseReferenceKdTree = s->use_kd != 0;
         rt->Antialiasing = p->aa_mode == 1 ? AbstractRaycaster::AAMode::SSAA : AbstractRaycaster::AAMode::None;
         unsigned int *px = rt->RenderSync(s->scene.get());
         s->last_stats = rt->GetLastStats();
@@ -256,6 +259,7 @@ int sb_render(sb_scene *s, const sb_render_params *p, uint32_t *pixels, int32_t 
             std::memset(&prm, 0, sizeof prm);
             prm.width = (uint32_t)W; prm.height = (uint32_t)H; prm.max_recursion = 0; prm.aa_mode = 0;
             prm.renderer = RTHIP_RENDER_DEBUG_NORMAL; prm.part_index = 0; prm.part_count = 1;
+            prm.accel = s->use_kd;
             std::vector<uint32_t> tmp(W * H);
             sh.resize(W * H); tr.resize(W * H);
             rc = rthip_render(s->ctx, &cam, &prm, tmp.data(), sh.data(), tr.data());

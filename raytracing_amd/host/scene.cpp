@@ -2,6 +2,7 @@
 // caches (Scene.cpp:509-523) and the kd-tree with the reference's splitting rules
 // (Scene.cpp:18-95), emitted directly in the flat pre-order layout the device walks.
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 
 #include "re/scene.hpp"
@@ -159,6 +160,162 @@ struct KdBuilder {
 };
 }  // namespace
 
+namespace {
+// Binned-SAH BVH builder (16 bins, 3 axes).  Boxes are exact fp64 while building and rounded
+// OUTWARD (plus one ulp) to fp32 when stored, so the device's fp32 slab test stays conservative.
+struct BvhBuilder {
+    static constexpr int kBins = 16;
+    static constexpr uint32_t kMaxLeaf = 8;
+    struct Box {
+        double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+        void Grow(const double *l, const double *h) {
+            for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], l[a]); hi[a] = std::max(hi[a], h[a]); }
+        }
+        void Grow(const Box &b) { Grow(b.lo, b.hi); }
+        double Area() const {
+            double dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+            return dx < 0 ? 0.0 : 2 * (dx * dy + dx * dz + dy * dz);
+        }
+    };
+    const std::vector<Triangle> &tris;
+    BvhFlat &out;
+    std::vector<double> tlo, thi, cen;  // 3 per triangle
+
+    static float Down(double x) {
+        float f = (float)x;
+        if ((double)f > x) f = std::nextafterf(f, -INFINITY);
+        return std::nextafterf(f, -INFINITY);
+    }
+    static float Up(double x) {
+        float f = (float)x;
+        if ((double)f < x) f = std::nextafterf(f, INFINITY);
+        return std::nextafterf(f, INFINITY);
+    }
+    void Prepare() {
+        const size_t n = tris.size();
+        tlo.resize(3 * n); thi.resize(3 * n); cen.resize(3 * n);
+        out.order.resize(n);
+        double amax = 0;
+        for (size_t i = 0; i < n; i++) {
+            out.order[i] = (uint32_t)i;
+            for (int a = 0; a < 3; a++) {
+                double v0 = tris[i].Vertices[0][a], v1 = tris[i].Vertices[1][a], v2 = tris[i].Vertices[2][a];
+                double l = std::min(v0, std::min(v1, v2)), h = std::max(v0, std::max(v1, v2));
+                tlo[3 * i + a] = l; thi[3 * i + a] = h; cen[3 * i + a] = 0.5 * (l + h);
+                amax = std::max(amax, std::max(std::fabs(l), std::fabs(h)));
+            }
+        }
+        out.abs_max = Up(amax);
+    }
+    Box BoundsOf(uint32_t lo, uint32_t hi) const {
+        Box b;
+        for (uint32_t i = lo; i < hi; i++) b.Grow(&tlo[3 * out.order[i]], &thi[3 * out.order[i]]);
+        return b;
+    }
+    // builds the subtree over order[lo,hi); returns the child word and its box
+    uint32_t Build(uint32_t lo, uint32_t hi, unsigned depth, Box &box) {
+        box = BoundsOf(lo, hi);
+        const uint32_t n = hi - lo;
+        out.depth = std::max(out.depth, depth);
+        auto leaf = [&]() { return RTHIP_BVH_LEAF | ((n - 1) << RTHIP_BVH_COUNT_SHIFT) | lo; };
+        if (n <= 1 || (n <= kMaxLeaf && depth >= RTHIP_BVH_MAX_DEPTH - 2)) return leaf();
+        Box cb;  // centroid bounds
+        for (uint32_t i = lo; i < hi; i++) cb.Grow(&cen[3 * out.order[i]], &cen[3 * out.order[i]]);
+        int best_axis = -1, best_bin = 0;
+        double best_cost = 1e300;
+        if (depth < 40) {
+            for (int a = 0; a < 3; a++) {
+                const double ext = cb.hi[a] - cb.lo[a];
+                if (!(ext > 0)) continue;
+                Box bb[kBins];
+                uint32_t cnt[kBins] = {0};
+                const double k = kBins / ext;
+                for (uint32_t i = lo; i < hi; i++) {
+                    const uint32_t t = out.order[i];
+                    int b = (int)((cen[3 * t + a] - cb.lo[a]) * k);
+                    b = b < 0 ? 0 : (b >= kBins ? kBins - 1 : b);
+                    cnt[b]++;
+                    bb[b].Grow(&tlo[3 * t], &thi[3 * t]);
+                }
+                double right_area[kBins];
+                uint32_t right_cnt[kBins];
+                Box acc;
+                uint32_t c = 0;
+                for (int b = kBins - 1; b > 0; b--) {
+                    acc.Grow(bb[b]); c += cnt[b];
+                    right_area[b] = acc.Area(); right_cnt[b] = c;
+                }
+                acc = Box(); c = 0;
+                for (int b = 0; b < kBins - 1; b++) {
+                    acc.Grow(bb[b]); c += cnt[b];
+                    if (c == 0 || right_cnt[b + 1] == 0) continue;
+                    const double cost = acc.Area() * c + right_area[b + 1] * right_cnt[b + 1];
+                    if (cost < best_cost) { best_cost = cost; best_axis = a; best_bin = b; }
+                }
+            }
+        }
+        // SAH says "do not split" only matters for small groups: a triangle test costs ~2.5 box steps
+        if (best_axis >= 0 && n <= 4) {
+            const double split_cost = 1.0 + 2.5 * best_cost / std::max(box.Area(), 1e-300);
+            if (split_cost >= 2.5 * n) return leaf();
+        }
+        uint32_t mid;
+        if (best_axis >= 0) {
+            const int a = best_axis;
+            const double k = kBins / (cb.hi[a] - cb.lo[a]), base = cb.lo[a];
+            auto first_right = std::partition(out.order.begin() + lo, out.order.begin() + hi, [&](uint32_t t) {
+                int b = (int)((cen[3 * t + a] - base) * k);
+                b = b < 0 ? 0 : (b >= kBins ? kBins - 1 : b);
+                return b <= best_bin;
+            });
+            mid = (uint32_t)(first_right - out.order.begin());
+        } else {
+            mid = lo;
+        }
+        if (mid == lo || mid == hi) {  // coincident centroids or depth guard: median split on the widest axis
+            if (n <= kMaxLeaf && best_axis < 0 && depth < 40) return leaf();
+            int a = 0;
+            for (int k2 = 1; k2 < 3; k2++)
+                if (cb.hi[k2] - cb.lo[k2] > cb.hi[a] - cb.lo[a]) a = k2;
+            mid = lo + n / 2;
+            std::nth_element(out.order.begin() + lo, out.order.begin() + mid, out.order.begin() + hi,
+                             [&](uint32_t x, uint32_t y) { return cen[3 * x + a] < cen[3 * y + a]; });
+        }
+        if (n > kMaxLeaf && depth >= RTHIP_BVH_MAX_DEPTH - 2) {  // cannot happen with median halving below 2^60 triangles
+            mid = lo + n / 2;
+        }
+        const uint32_t me = (uint32_t)out.nodes.size();
+        out.nodes.emplace_back();
+        Box b0, b1;
+        const uint32_t c0 = Build(lo, mid, depth + 1, b0);
+        const uint32_t c1 = Build(mid, hi, depth + 1, b1);
+        Fill(me, c0, b0, c1, &b1);
+        return me;
+    }
+    void Fill(uint32_t me, uint32_t c0, const Box &b0, uint32_t c1, const Box *b1) {
+        BvhFlat::Node &nd = out.nodes[me];
+        for (int a = 0; a < 3; a++) {
+            nd.lo0[a] = Down(b0.lo[a]); nd.hi0[a] = Up(b0.hi[a]);
+            nd.lo1[a] = b1 ? Down(b1->lo[a]) : INFINITY;
+            nd.hi1[a] = b1 ? Up(b1->hi[a]) : -INFINITY;
+        }
+        nd.child0 = c0; nd.child1 = c1;
+        nd.pad[0] = nd.pad[1] = 0;
+    }
+    void Run() {
+        out = BvhFlat();
+        if (tris.empty()) return;
+        Prepare();
+        Box root;
+        const uint32_t w = Build(0, (uint32_t)tris.size(), 0, root);
+        if (w & RTHIP_BVH_LEAF) {  // tiny mesh: a root node whose first child is the single leaf
+            out.nodes.emplace_back();
+            Fill(0, w, root, RTHIP_BVH_LEAF, nullptr);
+        }
+    }
+};
+}  // namespace
+
 void Mesh::Compile() {
     if (!m_Invalidated) return;
     // the bounding box starts at (0,0,0)/(0,0,0) and is never reset (Scene.cpp:391-406, Common.h:212)
@@ -175,6 +332,8 @@ void Mesh::Compile() {
     for (size_t i = 0; i < all.size(); i++) all[i] = (uint32_t)i;
     KdBuilder builder{m_Triangles, m_KdTree};
     builder.Build(all, m_BoundingBox, 0);
+    BvhBuilder bvh{m_Triangles, m_Bvh, {}, {}, {}};
+    bvh.Run();
     m_Invalidated = false;
 }
 

@@ -11,11 +11,14 @@
 
 using namespace rtc;
 
+static int g_accel = 0;
+extern "C" void hc_set_accel(int a) { g_accel = a; }
 static SceneView view_of(const rthip_scene_desc *s) {
     SceneView v;
     v.shapes = s->shapes; v.n_shapes = s->n_shapes; v.meshes = s->meshes;
-    v.kd_nodes = s->kd_nodes; v.kd_bounds = s->kd_bounds; v.kd_refs = s->kd_refs;
-    v.tris = s->tris; v.tri_normals = s->tri_normals; v.materials = s->materials; v.noises = s->noises;
+    v.kd_nodes = s->kd_nodes; v.kd_bounds = s->kd_bounds; v.kd_refs = s->kd_refs; v.kd_planes = s->kd_planes;
+    v.tris = s->tris; v.tri_normals = s->tri_normals; v.bvh_nodes = s->bvh_nodes; v.bvh_tris = s->bvh_tris;
+    v.bvh_tri_index = s->bvh_tri_index; v.accel = g_accel; v.materials = s->materials; v.noises = s->noises;
     v.perlin_tables = s->perlin_tables; v.worley_points = s->worley_points;
     v.lights = s->lights; v.n_lights = s->n_lights; v.bg = s->background;
     return v;
@@ -33,7 +36,7 @@ int hc_render(const rthip_scene_desc *scene, const rthip_camera *cam, const rthi
         uint32_t stack_mem[128];
         KdStack st{stack_mem, 1, 128, 0};
         uint64_t mine = 0;
-        KdCounters kc = {0, 0, 0};
+        KdCounters kc = {0, 0, 0, 0, 0, 0};
         for (;;) {
             uint32_t y = next.fetch_add(1);
             if (y >= p->height) break;

@@ -127,6 +127,38 @@ def test_known_answers_of_single_device_functions(golden, name):
     assert n_checked > 0
 
 
+@pytest.mark.parametrize("name", ["cfg3", "cfg3close", "nested"])
+def test_reference_kdtree_traversal_gives_the_same_frames(golden, name):
+    """accel = 1: the literal flattening of KDTreeTriangle (ordered, pruned walk with the reference's box test)"""
+    mk, w, h, kw = FRAME_CASES[name]
+    hs = host.HostScene(mk())
+    hs.set_accel(True)
+    got = hs.render(w, h, ids=True, **kw)
+    f = golden["frames"]
+    diff, ids_bad = assert_frame_parity(got, f[name + "_pixels"], f[name + "_shape"].astype(np.int32), f[name + "_tri"], name)
+    assert diff == 0 and ids_bad == 0 and got["rays"] == int(f[name + "_rays"][0])
+
+
+def test_rays_in_a_kd_split_plane_follow_the_reference(oracle_lib):
+    """A ray with an exactly-zero direction component whose origin lies exactly on a kd box plane makes the
+    reference's slab test evaluate 0/0 (Common.cpp:349-356): it then misses geometry a geometric structure
+    finds.  The device routes exactly those rays through the kd-tree (kd_degenerate_ray)."""
+    sd = scenes.SceneDesc("grid mesh symmetric about x = 0, camera on the plane x = 0")
+    m = sd.uniform_material(0x88aa66, 0.8)
+    v, n = scenes.heightfield_mesh(cells=32, seed=5, extent=4.0)
+    sd.mesh(m, v, n, scenes.NORMAL_VERTEX)
+    sd.directional_light(0xffffff, 1, 2, 1)
+    sd.color_background(0x102030)
+    sd.look_at((0, 5, 9), (0, 0, 0))
+    w, h = 128, 96
+    got = host.HostScene(sd).render(w, h, max_recursion=2, ids=True)
+    ref = sd.build(oracle_lib).render(w, h, max_recursion=2, ids=True, threads=8)
+    col = w // 2
+    assert (ref["shape"][:, col] < 0).sum() > (ref["shape"][:, col - 1] < 0).sum(), "fixture no longer degenerate"
+    diff, ids_bad = assert_frame_parity(got, ref["pixels"], ref["shape"], ref["tri"], sd.name)
+    assert diff == 0 and ids_bad == 0
+
+
 def test_device_matches_oracle_on_fresh_random_views(oracle_lib):
     """same seeded inputs through the oracle and the device, views that are not in the fixtures"""
     rng = np.random.default_rng(2024)

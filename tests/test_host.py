@@ -46,10 +46,13 @@ def _hostcore():
     return L
 
 
+@pytest.mark.parametrize("accel", [0, 1], ids=["bvh", "refkd"])
 @pytest.mark.parametrize("name", list(FRAME_CASES))
-def test_flattener_plus_device_core_on_host_match_golden(host_lib, golden, name):
-    """the flattened scene (product host code) rendered by rt_core.hpp compiled with g++ (test build)"""
+def test_flattener_plus_device_core_on_host_match_golden(host_lib, golden, name, accel):
+    """the flattened scene (product host code) rendered by rt_core.hpp compiled with g++ (test build),
+    through the BVH and through the reference kd-tree"""
     mk, w, h, kw = FRAME_CASES[name]
+    _hostcore().hc_set_accel(accel)
     hs = host.HostScene(mk())
     cam = hs.camera(w, h)
     prm = device.make_params(w, h, kw.get("max_recursion", 3), kw.get("aa", 0), kw.get("renderer", 0))
@@ -107,3 +110,44 @@ def test_scene_generators_are_deterministic():
     assert (np.cross(e0, e1)[:, 1] > 0).all()
     x = np.linspace(-20, 20, 2001)
     assert np.abs(scenes.det_sin(x) - np.sin(x)).max() < 1e-6  # a fixed polynomial: the generator's own definition
+
+
+def test_bvh_is_complete_and_conservative(host_lib):
+    """every triangle appears in exactly one leaf and lies inside the (outward-rounded fp32) boxes on its path"""
+    import ctypes as C
+    hs = host.HostScene(scenes.config(3)[0])
+    desc = hs.flatten()
+    # read the flattened arrays back through the struct layout of include/rthip.h
+    class Desc(C.Structure):
+        _fields_ = [("shapes", C.c_void_p), ("n_shapes", C.c_uint32), ("meshes", C.c_void_p), ("n_meshes", C.c_uint32),
+                    ("kd_nodes", C.c_void_p), ("n_kd_nodes", C.c_uint64), ("kd_bounds", C.c_void_p), ("kd_refs", C.c_void_p),
+                    ("n_kd_refs", C.c_uint64), ("kd_planes", C.c_void_p), ("n_kd_planes", C.c_uint64), ("tris", C.c_void_p),
+                    ("n_tris", C.c_uint64), ("tri_normals", C.c_void_p), ("bvh_nodes", C.c_void_p), ("n_bvh_nodes", C.c_uint64),
+                    ("bvh_tris", C.c_void_p), ("bvh_tri_index", C.c_void_p)]
+    d = Desc.from_address(desc)
+    n_tris, n_nodes = d.n_tris, d.n_bvh_nodes
+    assert n_tris == 4968 and n_nodes > 1000
+    nodes = np.frombuffer((C.c_char * (64 * n_nodes)).from_address(d.bvh_nodes), dtype=np.dtype(
+        [("lo0", "<f4", 3), ("hi0", "<f4", 3), ("lo1", "<f4", 3), ("hi1", "<f4", 3), ("c0", "<u4"), ("c1", "<u4"), ("pad", "<u4", 2)]))
+    index = np.frombuffer((C.c_uint32 * n_tris).from_address(d.bvh_tri_index), dtype=np.uint32)
+    assert sorted(index.tolist()) == list(range(n_tris))            # a permutation: no triangle lost or duplicated
+    verts = scenes.load_bunny()[0].reshape(-1, 3, 3)
+    seen = np.zeros(n_tris, bool)
+    stack = [(0, np.full(3, -np.inf), np.full(3, np.inf))]
+    while stack:
+        ni, lo, hi = stack.pop()
+        nd = nodes[ni]
+        for c, blo, bhi in ((nd["c0"], nd["lo0"], nd["hi0"]), (nd["c1"], nd["lo1"], nd["hi1"])):
+            if not (blo[0] <= bhi[0]):
+                continue                                            # absent child
+            clo, chi = np.maximum(lo, blo.astype(np.float64)), np.minimum(hi, bhi.astype(np.float64))
+            if c & 0x80000000:
+                first, cnt = int(c & 0x0fffffff), int((c >> 28) & 7) + 1
+                for k in range(first, first + cnt):
+                    t = index[k]
+                    assert not seen[t]
+                    seen[t] = True
+                    assert (verts[t] >= clo).all() and (verts[t] <= chi).all(), "triangle sticks out of its boxes"
+            else:
+                stack.append((int(c), clo, chi))
+    assert seen.all()

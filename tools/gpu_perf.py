@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Perf + regression harness for kernel work: ms/frame (HIP events, output resident in HBM) of the
+BASELINE configs, with a hash of every frame so that a faster kernel that changes a pixel is caught."""
+import hashlib, json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("RTHIP_PROFILE_LAUNCHES", "1")
+import numpy as np
+import torch
+from raytracing_amd import device, host, scenes
+
+HASHES = os.path.join(scenes.GOLDEN_DIR, "frame_hashes.json")
+known = json.load(open(HASHES)) if os.path.exists(HASHES) else {}
+cases = [("cfg3", lambda: scenes.config(3), {}), ("cfg3close", lambda: scenes.config(3, cam_z=2.2), {}),
+         ("cfg2", lambda: scenes.config(2), {}), ("cfg4", lambda: scenes.config(4), {})]
+only = sys.argv[1:] or [c[0] for c in cases]
+out = {}
+for name, mk, _ in cases:
+    if name not in only:
+        continue
+    sd, kw = mk()
+    t0 = time.time()
+    hs = host.HostScene(sd)
+    desc = hs.flatten()
+    t1 = time.time()
+    ctx = device.Context(0)
+    ctx.upload(desc)
+    W, H, mr = kw["width"], kw["height"], kw["max_recursion"]
+    cam = hs.camera(W, H)
+    fb = torch.zeros(W * H, dtype=torch.int32, device="cuda")
+    prm = device.make_params(W, H, mr)
+    best = 1e9
+    for i in range(6):
+        ctx.render_device(cam, prm, fb.data_ptr(), sync=True)
+        s = ctx.stats()
+        best = min(best, s.ms_total)
+    rays = s.rays_primary + s.rays_shadow + s.rays_reflect
+    h = hashlib.sha256(fb.cpu().numpy().tobytes()).hexdigest()[:16]
+    ok = known.get(name) in (None, h)
+    print(f"{name}: {W}x{H} maxrec {mr} best {best:.3f} ms  rays {rays}  {rays/best/1e3:.0f} Mrays/s  trace {s.ms_trace:.3f} ms/{s.launches_trace} launches  "
+          f"flatten+kd {t1-t0:.2f}s  hash {h} {'OK' if ok else 'MISMATCH vs ' + known.get(name)}", flush=True)
+    out[name] = h
+    ctx.close()
+if "--record" in os.environ.get("PERF_FLAGS", ""):
+    known.update(out)
+    json.dump(known, open(os.path.join("gpurun_out", "frame_hashes.json"), "w"), indent=1)
