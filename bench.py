@@ -9,7 +9,7 @@ region; every step traces the whole frame.  With N > 1 the frame is partitioned 
 HBM, the buffers are all-gathered over RCCL and assembled into the frame on the device; total work
 is fixed as N grows ("strong" scaling).
 
-Prints ONE JSON line (rank 0).  Extra objects: "roofline" (dominant kernel k_bounce, algorithmic
+Prints ONE JSON line (rank 0).  Extra objects: "roofline" (dominant kernel k_trace, algorithmic
 bytes from SURVEY.md §8d's per-ray formula with counts measured on this frame) and "cpu_baseline"
 (the genuine reference compiled in oracle/_ref — or the C oracle port — timed on the host cores).
 """
@@ -159,7 +159,7 @@ def main():
                        "frame_checksum": checksum},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "k_bounce", "launches_per_frame": int(st.launches_trace), "avg_launch_ms": launch_ms,
+                         "kernel": "k_trace", "launches_per_frame": int(st.launches_trace), "avg_launch_ms": launch_ms,
                          "algorithmic_bytes_per_frame_rank0": int(abytes),
                          "note": "the whole flattened bunny tree (~1.5 MB) is L2-resident: the kernel is fp64-VALU/latency bound, "
                                  "not HBM bound; see DESIGN.md"},

@@ -19,7 +19,7 @@
 #define RT_HD_NOINLINE __host__ __device__ __noinline__
 #else
 #define RT_HD inline
-#define RT_HD_NOINLINE
+#define RT_HD_NOINLINE inline
 #endif
 
 namespace rtc {
@@ -189,7 +189,7 @@ RT_HD double noise_wrap(double x, double domain) {
     x = (double)fmodf((float)x, (float)domain) / domain;
     return x < 0 ? 1.0 + x : x;
 }
-RT_HD double noise_sample(const SceneView &sv, int32_t ni, V3 p) {
+RT_HD double noise_sample(const SceneView &sv, const uint8_t *tabs, int32_t ni, V3 p) {
     const rthip_noise &n = sv.noises[ni];
     V3 q = mk(noise_wrap(p.x, n.domain), noise_wrap(p.y, n.domain), noise_wrap(p.z, n.domain));
     switch (n.type) {
@@ -198,11 +198,11 @@ RT_HD double noise_sample(const SceneView &sv, int32_t ni, V3 p) {
         return (double)(t2 ^ t0);
     }
     case RTHIP_NOISE_PERLIN:
-        return perlin_normalized(sv.perlin_tables + 256 * (size_t)n.table, n.octaves, n.persistance, q);
+        return perlin_normalized(tabs + 256 * (size_t)n.table, n.octaves, n.persistance, q);
     case RTHIP_NOISE_WORLEY:
         return worley_normalized(sv.worley_points + 3 * (size_t)n.points_base, n.divisions, n.step, q);
     default: {  // Marble.cpp:11-15
-        double f = perlin_normalized(sv.perlin_tables + 256 * (size_t)n.table, n.octaves, n.persistance, q) * n.turbolence;
+        double f = perlin_normalized(tabs + 256 * (size_t)n.table, n.octaves, n.persistance, q) * n.turbolence;
         return fabs(sin(f * n.frequency * (double)3.141592f));
     }
     }
@@ -212,7 +212,7 @@ RT_HD double noise_sample(const SceneView &sv, int32_t ni, V3 p) {
 // Evaluates the postfix program ending at op `root`: Lerp<Color> = a*(1-t) (+) b*t with clamping
 // Color ops, Lerp<real> unclamped (Material.cpp:21-29).  Noise is sampled once per INTERP node
 // (the reference re-samples it per query; Sample is a pure function of the point).
-RT_HD void material_eval(const SceneView &sv, int32_t root, V3 p, Col &color, double &absorptance) {
+RT_HD void material_eval(const SceneView &sv, const uint8_t *tabs, int32_t root, V3 p, Col &color, double &absorptance) {
     const rthip_matop &r = sv.materials[root];
     if (r.op == RTHIP_MAT_UNIFORM) {
         color = c_from(r.color);
@@ -221,7 +221,7 @@ RT_HD void material_eval(const SceneView &sv, int32_t root, V3 p, Col &color, do
     }
     if (root - r.first_op == 2) {  // INTERP of two UNIFORMs: no stack needed
         const rthip_matop &a = sv.materials[root - 2], &b = sv.materials[root - 1];
-        double t = noise_sample(sv, r.noise, p);
+        double t = noise_sample(sv, tabs, r.noise, p);
         color = c_add(c_scale(c_from(a.color), 1 - t), c_scale(c_from(b.color), t));
         absorptance = lerp(a.absorptance, b.absorptance, t);
         return;
@@ -238,7 +238,7 @@ RT_HD void material_eval(const SceneView &sv, int32_t root, V3 p, Col &color, do
                 sp++;
             }
         } else if (sp >= 2) {
-            double t = noise_sample(sv, m.noise, p);
+            double t = noise_sample(sv, tabs, m.noise, p);
             Col a = cs[sp - 2], b = cs[sp - 1];
             double aa = as[sp - 2], ab = as[sp - 1];
             sp--;
@@ -252,7 +252,7 @@ RT_HD void material_eval(const SceneView &sv, int32_t root, V3 p, Col &color, do
 
 // ----------------------------------------------------------------------------- background (B1, B2)
 // Scene.cpp:111-151 SkyBox::GetColor; Scene.h:43-49 ColorBackground
-RT_HD Col background_color(const SceneView &sv, V3 direction) {
+RT_HD Col background_color(const SceneView &sv, const uint8_t *tabs, V3 direction) {
     const rthip_background &bg = sv.bg;
     if (bg.type == RTHIP_BG_NONE) return Col{0, 0, 0};  // Raytracer.cpp:296-299
     if (bg.type == RTHIP_BG_COLOR) return c_from(bg.color0);
@@ -261,7 +261,7 @@ RT_HD Col background_color(const SceneView &sv, V3 direction) {
     const float thresoldPlusBorder = thresold + border;
     V3 q = divs(add(direction, mk(1, 1, 1)), 2.0);
     V3 w = mk(noise_wrap(q.x, 1.0), noise_wrap(q.y, 1.0), noise_wrap(q.z, 1.0));
-    double sample = perlin_normalized(sv.perlin_tables + 256 * (size_t)bg.table, 8, 0.5, w);
+    double sample = perlin_normalized(tabs + 256 * (size_t)bg.table, 8, 0.5, w);
     Col color = c_mix(c_from(bg.color0), c_from(bg.color1), sample);
     if (bg.sun_light >= 0 && sv.lights[bg.sun_light].type == RTHIP_LIGHT_DIRECTIONAL) {
         const rthip_light &sun = sv.lights[bg.sun_light];
@@ -308,10 +308,11 @@ RT_HD bool plane_intersect(V3 n, V3 o, V3 d, V3 &point) {
     return true;
 }
 
+// Only what decides the argmin stays live during a traversal; the hit point and the barycentrics of the
+// winner are recomputed afterwards by tri_point (same arithmetic, so bit-identical), which keeps the
+// traversal loops small in registers.
 struct TriBest {
     double d;      // |O - P|^2 exactly as Scene.cpp:477
-    V3 point;
-    double u, v, w;
     uint32_t tri;  // mesh-relative triangle index
     uint32_t ref;  // position in the pre-order leaf-reference array (tie order)
     bool hit;
@@ -339,15 +340,26 @@ RT_HD void tri_test(const rthip_tri &t, V3 o, V3 d, uint32_t tri, uint32_t ref, 
         double dd = sqlen(sub(o, projection));
         if (dd < best.d || (best.hit && dd == best.d && ref < best.ref)) {
             best.d = dd;
-            best.point = projection;
-            best.u = u;
-            best.v = v;
-            best.w = w;
             best.tri = tri;
             best.ref = ref;
             best.hit = true;
         }
     }
+}
+
+// Hit point and barycentrics of a triangle already known to be hit (Scene.cpp:446-450, 495-507)
+RT_HD void tri_point(const rthip_tri &t, V3 o, V3 d, V3 &projection, double &u, double &v, double &w) {
+    V3 v0 = mk(t.v0[0], t.v0[1], t.v0[2]);
+    V3 nf = mk(t.face_normal[0], t.face_normal[1], t.face_normal[2]);
+    double distance = dot(sub(o, v0), nf);
+    double cosine = dot(d, nf);
+    projection = add(o, scale(d, distance / -cosine));
+    V3 v2 = sub(projection, v0);
+    double d20 = dot(v2, mk(t.e0[0], t.e0[1], t.e0[2]));
+    double d21 = dot(v2, mk(t.e1[0], t.e1[1], t.e1[2]));
+    v = (t.d11 * d20 - t.d01 * d21) * t.inv_den;
+    w = (t.d00 * d21 - t.d01 * d20) * t.inv_den;
+    u = 1.0 - v - w;
 }
 
 // Common.cpp:345-363 BoundingBox::Intersect on precomputed plane parameters
@@ -381,7 +393,7 @@ RT_HD bool kd_prunable(double t7, const TriBest &best) {
 // differs from its parent's in one plane (BoundingBox::Split, Common.cpp:313-338), so descending
 // costs one division; the six plane parameters are recomputed from the stored bounds on a pop.
 RT_HD void mesh_closest(const SceneView &sv, const rthip_mesh &m, V3 o, V3 d, KdStack &st, TriBest &best,
-                        KdCounters *cnt) {
+                                 KdCounters *cnt) {
     best.hit = false;
     best.d = DBL_MAX;
     best.tri = 0xffffffffu;
@@ -583,99 +595,188 @@ struct Hit {
     V3 point, local, normal;
 };
 
+// Shape::Intersect of one shape in its local frame: hit flag, local hit point, winning triangle
+// FAST = true: meshes go through the BVH only; a degenerate (ray, mesh) pair (kd_degenerate_ray) is not
+// walked but reported through `redo`, and the caller re-runs the whole ray with FAST = false, whose
+// instantiation also contains the reference kd-tree walk.  Keeping that rare path out of the hot
+// kernel keeps its register footprint and code size down.
+template <bool FAST>
+RT_HD bool shape_intersect(const SceneView &sv, const rthip_shape &sh, V3 lo, V3 ld, KdStack &st, V3 &p, int32_t &tri,
+                           bool &redo, KdCounters *cnt) {
+    tri = -1;
+    if (sh.type == RTHIP_SHAPE_SPHERE) return sphere_intersect(lo, ld, p);
+    if (sh.type == RTHIP_SHAPE_PLANE) return plane_intersect(mk(sh.plane_n[0], sh.plane_n[1], sh.plane_n[2]), lo, ld, p);
+    const rthip_mesh &m = sv.meshes[sh.mesh];
+    TriBest tb;
+    if (FAST) {
+        if (kd_degenerate_ray(sv, m, lo, ld)) {
+            redo = true;
+            return false;
+        }
+        mesh_closest_bvh(sv, m, lo, ld, st, tb, cnt);
+    } else {
+        if (sv.accel == 0 && !kd_degenerate_ray(sv, m, lo, ld))
+            mesh_closest_bvh(sv, m, lo, ld, st, tb, cnt);
+        else
+            mesh_closest(sv, m, lo, ld, st, tb, cnt);
+    }
+    if (!tb.hit) return false;
+    tri = (int32_t)tb.tri;
+    double u, v, w;
+    tri_point(sv.tris[m.tri_base + tb.tri], lo, ld, p, u, v, w);
+    return true;
+}
+
 // Scene::CastRay / CastRayRecursive (Scene.cpp:163-237) over the flat pre-order shape table:
 // per shape world->local ray, Intersect, local->world point, accept iff d^2 >= DBL_EPSILON
 // (Scene.cpp:200), keep the strictly smallest d^2 (earlier node wins ties, Scene.cpp:225).
-// any_hit: stop at the first accepted shape (CastShadowRay only consumes .Hit, Raytracer.cpp:305-310).
-RT_HD Hit cast_ray(const SceneView &sv, V3 o, V3 d, KdStack &st, bool any_hit, KdCounters *cnt) {
-    Hit best;
-    best.shape = -1;
-    best.tri = -1;
-    best.point = best.local = best.normal = mk(0, 0, 0);
+// Returns the winning shape (or -1) and its triangle; any_hit stops at the first accepted shape
+// (CastShadowRay only consumes .Hit, Raytracer.cpp:305-310).
+template <bool FAST>
+RT_HD int32_t cast_ray_id(const SceneView &sv, V3 o, V3 d, KdStack &st, bool any_hit, int32_t &best_tri, bool &redo,
+                          KdCounters *cnt) {
+    int32_t best = -1;
+    best_tri = -1;
     double hitDistance = DBL_MAX;
-    V3 best_local_normal = mk(0, 0, 0);
     for (uint32_t s = 0; s < sv.n_shapes; s++) {
         const rthip_shape &sh = sv.shapes[s];
         if (cnt) cnt->shapes++;
         V3 lo = xform(sh.inv, o, 1.0);
         V3 ld = normalized(xform(sh.inv, d, 0.0));
-        V3 p = mk(0, 0, 0), ln = mk(0, 0, 0);
-        int32_t tri = -1;
-        bool hit;
-        TriBest tb;
-        if (sh.type == RTHIP_SHAPE_SPHERE) {
-            hit = sphere_intersect(lo, ld, p);
-        } else if (sh.type == RTHIP_SHAPE_PLANE) {
-            hit = plane_intersect(mk(sh.plane_n[0], sh.plane_n[1], sh.plane_n[2]), lo, ld, p);
-        } else {
-            if (sv.accel == 0 && !kd_degenerate_ray(sv, sv.meshes[sh.mesh], lo, ld))
-                mesh_closest_bvh(sv, sv.meshes[sh.mesh], lo, ld, st, tb, cnt);
-            else
-                mesh_closest(sv, sv.meshes[sh.mesh], lo, ld, st, tb, cnt);
-            hit = tb.hit;
-            p = tb.point;
-            tri = (int32_t)tb.tri;
-        }
-        if (!hit) continue;
+        V3 p;
+        int32_t tri;
+        if (!shape_intersect<FAST>(sv, sh, lo, ld, st, p, tri, redo, cnt)) continue;
         V3 worldPoint = xform(sh.fwd, p, 1.0);
         double distance = sqlen(sub(o, worldPoint));
         if (!(distance >= DBL_EPSILON)) continue;
         if (!(distance < hitDistance)) continue;
         hitDistance = distance;
-        best.shape = (int32_t)s;
-        best.tri = tri;
-        best.point = worldPoint;
-        best.local = p;
-        if (any_hit) return best;
-        if (sh.type == RTHIP_SHAPE_SPHERE) {
-            ln = normalized(p);  // Scene.cpp:327
-        } else if (sh.type == RTHIP_SHAPE_PLANE) {
-            ln = mk(sh.plane_n[0], sh.plane_n[1], sh.plane_n[2]);  // Scene.cpp:359
-        } else {
-            const rthip_mesh &m = sv.meshes[sh.mesh];
-            if (m.normal_mode == 0) {
-                const rthip_tri &t = sv.tris[m.tri_base + tb.tri];
-                ln = mk(t.face_normal[0], t.face_normal[1], t.face_normal[2]);  // Scene.cpp:458
-            } else {  // Scene.cpp:462
-                if (cnt) cnt->mesh_hits++;
-                const double *n = sv.tri_normals + 9 * (size_t)(m.tri_base + tb.tri);
-                ln = normalized(add(add(scale(mk(n[0], n[1], n[2]), tb.u), scale(mk(n[3], n[4], n[5]), tb.v)),
-                                    scale(mk(n[6], n[7], n[8]), tb.w)));
-            }
-        }
-        best_local_normal = ln;
+        best = (int32_t)s;
+        best_tri = tri;
+        if (any_hit) break;
     }
-    if (best.shape >= 0 && !any_hit)
-        best.normal = normalized(xform(sv.shapes[best.shape].nrm, best_local_normal, 0.0));  // Scene.cpp:208
     return best;
 }
 
+// Point, local point and world normal of the winner (Scene.cpp:196-209, 327, 359, 456-463), recomputed
+// with the arithmetic the search used, so the values are the ones the reference stores in RaycastResult.
+RT_HD void hit_details(const SceneView &sv, V3 o, V3 d, int32_t shape, int32_t tri, Hit &h, KdCounters *cnt) {
+    const rthip_shape &sh = sv.shapes[shape];
+    V3 lo = xform(sh.inv, o, 1.0);
+    V3 ld = normalized(xform(sh.inv, d, 0.0));
+    V3 p = mk(0, 0, 0), ln;
+    if (sh.type == RTHIP_SHAPE_SPHERE) {
+        sphere_intersect(lo, ld, p);
+        ln = normalized(p);
+    } else if (sh.type == RTHIP_SHAPE_PLANE) {
+        ln = mk(sh.plane_n[0], sh.plane_n[1], sh.plane_n[2]);
+        plane_intersect(ln, lo, ld, p);
+    } else {
+        const rthip_mesh &m = sv.meshes[sh.mesh];
+        const rthip_tri &t = sv.tris[m.tri_base + (uint32_t)tri];
+        double u, v, w;
+        tri_point(t, lo, ld, p, u, v, w);
+        if (m.normal_mode == 0) {
+            ln = mk(t.face_normal[0], t.face_normal[1], t.face_normal[2]);
+        } else {
+            if (cnt) cnt->mesh_hits++;
+            const double *n = sv.tri_normals + 9 * (size_t)(m.tri_base + (uint32_t)tri);
+            ln = normalized(add(add(scale(mk(n[0], n[1], n[2]), u), scale(mk(n[3], n[4], n[5]), v)), scale(mk(n[6], n[7], n[8]), w)));
+        }
+    }
+    h.shape = shape;
+    h.tri = tri;
+    h.local = p;
+    h.point = xform(sh.fwd, p, 1.0);
+    h.normal = normalized(xform(sh.nrm, ln, 0.0));
+}
+
+RT_HD Hit cast_ray(const SceneView &sv, V3 o, V3 d, KdStack &st, bool any_hit, KdCounters *cnt) {
+    Hit h;
+    h.point = h.local = h.normal = mk(0, 0, 0);
+    bool redo = false;
+    h.shape = cast_ray_id<false>(sv, o, d, st, any_hit, h.tri, redo, cnt);
+    if (h.shape >= 0 && !any_hit) hit_details(sv, o, d, h.shape, h.tri, h, cnt);
+    return h;
+}
+
 // ----------------------------------------------------------------------------- shading (R4-R6)
-struct Bounce {
+// One level of Raytracer::RecursiveRaytrace (Raytracer.cpp:187-303) is split into the two wavefront
+// stages the frame kernels run: trace_stage (all scene queries of the level: the closest hit and one
+// shadow query per light) and shade_stage (material/noise, Lambert terms, the reflected ray).
+struct HitRec {
+    int32_t shape, tri;     // -1 = miss
+    uint32_t shadow_mask;   // bit l set: CastShadowRay towards light l hit something (Raytracer.cpp:227, 232)
+    V3 local, normal;       // RaycastResult.LocalPoint / .Normal (Scene.cpp:205-209)
+};
+
+// Closest hit, then the shadow queries.  The reference only casts shadow rays when absorptance > 0
+// (Raytracer.cpp:208); casting them unconditionally cannot change the image (their results are unused
+// in that case) and keeps material evaluation out of the traversal kernel.  One cast_ray call site
+// serves both query kinds so the traversal code is instantiated once.
+// Returns false (FAST only) when the ray met a degenerate (ray, mesh) pair and must be re-run with FAST = false.
+template <bool FAST>
+RT_HD bool trace_stage(const SceneView &sv, V3 o, V3 d, KdStack &st, HitRec &h, KdCounters *cnt) {
+    bool redo = false;
+    h.shape = -1;
+    h.tri = -1;
+    h.shadow_mask = 0;
+    h.local = h.normal = mk(0, 0, 0);
+    V3 point = mk(0, 0, 0);
+    for (int32_t q = -1; q < (int32_t)sv.n_lights; q++) {
+        V3 ro = o, rd = d;
+        if (q >= 0) {
+            if (h.shape < 0) break;
+            const rthip_light &light = sv.lights[q];
+            if (!light.enabled || light.type == RTHIP_LIGHT_AMBIENT) continue;  // Raytracer.cpp:213, 234-237
+            ro = point;
+            if (light.type == RTHIP_LIGHT_DIRECTIONAL)
+                rd = mk(light.direction[0], light.direction[1], light.direction[2]);
+            else
+                rd = normalized(sub(mk(light.position[0], light.position[1], light.position[2]), point));
+        }
+        int32_t tri;
+        int32_t shape = cast_ray_id<FAST>(sv, ro, rd, st, q >= 0, tri, redo, cnt);
+        if (FAST && redo) return false;
+        if (q < 0) {
+            if (shape >= 0) {
+                Hit c;
+                hit_details(sv, o, d, shape, tri, c, cnt);
+                h.shape = shape;
+                h.tri = tri;
+                h.local = c.local;
+                h.normal = c.normal;
+                point = c.point;
+            }
+        } else if (shape >= 0) {
+            h.shadow_mask |= 1u << q;
+        }
+    }
+    return true;
+}
+
+struct ShadeOut {
     Col color;      // miss: background; hit: directLighting (Raytracer.cpp:192, 269-270)
     double refl;    // reflectance applied to the child's colour (Raytracer.cpp:283)
     bool spawn;     // a reflected ray follows (Raytracer.cpp:276)
     V3 child_o, child_d;
-    int32_t shape, tri;
-    uint32_t shadow_rays;
+    uint32_t shadow_rays;  // CastShadowRay calls the reference makes for this hit
 };
 
-// One level of Raytracer::RecursiveRaytrace (Raytracer.cpp:187-303) without the recursive call:
-// closest hit, per-light shadow query + Lambert term, and the reflected ray if any.
-RT_HD void bounce(const SceneView &sv, V3 ro, V3 rd, bool may_reflect, KdStack &st, Bounce &out, KdCounters *cnt) {
-    Hit h = cast_ray(sv, ro, rd, st, false, cnt);
-    out.shape = h.shape;
-    out.tri = h.tri;
+RT_HD void shade_stage(const SceneView &sv, const uint8_t *tabs, const HitRec &h, V3 rd, bool may_reflect, ShadeOut &out) {
     out.spawn = false;
     out.refl = 0.0;
     out.shadow_rays = 0;
+    out.child_o = out.child_d = mk(0, 0, 0);
     if (h.shape < 0) {
-        out.color = background_color(sv, rd);
+        out.color = background_color(sv, tabs, rd);
         return;
     }
+    const rthip_shape &sh = sv.shapes[h.shape];
+    V3 point = xform(sh.fwd, h.local, 1.0);  // worldPoint, recomputed exactly as Scene.cpp:196
     Col albedo;
     double absorptance;
-    material_eval(sv, sv.shapes[h.shape].material, h.local, albedo, absorptance);
+    material_eval(sv, tabs, sh.material, h.local, albedo, absorptance);
     double reflectance = 1.0 - absorptance;  // Material.cpp:9-12
     Col direct = Col{0, 0, 0};
     if (absorptance > 0) {
@@ -684,20 +785,15 @@ RT_HD void bounce(const SceneView &sv, V3 ro, V3 rd, bool may_reflect, KdStack &
             if (!light.enabled) continue;
             V3 ldir = mk(light.direction[0], light.direction[1], light.direction[2]);
             V3 lpos = mk(light.position[0], light.position[1], light.position[2]);
-            bool shadowed = false;
-            if (light.type == RTHIP_LIGHT_DIRECTIONAL) {
+            if (light.type != RTHIP_LIGHT_AMBIENT) {
                 out.shadow_rays++;
-                shadowed = cast_ray(sv, h.point, ldir, st, true, cnt).shape >= 0;
-            } else if (light.type == RTHIP_LIGHT_POINT) {
-                out.shadow_rays++;
-                shadowed = cast_ray(sv, h.point, normalized(sub(lpos, h.point)), st, true, cnt).shape >= 0;
+                if (h.shadow_mask & (1u << li)) continue;
             }
-            if (shadowed) continue;
             double diffuseFactor = 0.0;
             if (light.type == RTHIP_LIGHT_DIRECTIONAL) {
                 diffuseFactor = (double)fmaxf(0.0f, (float)dot(h.normal, ldir));  // Raytracer.cpp:252
             } else if (light.type == RTHIP_LIGHT_POINT) {                        // Raytracer.cpp:255-259
-                V3 lightVector = sub(lpos, h.point);
+                V3 lightVector = sub(lpos, point);
                 V3 direction = normalized(lightVector);
                 double distance = length(lightVector);
                 double attenuation = 1.0 - ((distance * distance) / (light.attenuation * light.attenuation));
@@ -713,9 +809,33 @@ RT_HD void bounce(const SceneView &sv, V3 ro, V3 rd, bool may_reflect, KdStack &
     if (reflectance > 0 && may_reflect) {
         out.spawn = true;
         out.refl = reflectance;
-        out.child_o = h.point;
+        out.child_o = point;
         out.child_d = reflect(rd, h.normal);
     }
+}
+
+struct Bounce {
+    Col color;
+    double refl;
+    bool spawn;
+    V3 child_o, child_d;
+    int32_t shape, tri;
+    uint32_t shadow_rays;
+};
+// both stages back to back for one ray (probes and the host-compiled test build)
+RT_HD void bounce(const SceneView &sv, V3 ro, V3 rd, bool may_reflect, KdStack &st, Bounce &out, KdCounters *cnt) {
+    HitRec h;
+    trace_stage<false>(sv, ro, rd, st, h, cnt);
+    ShadeOut so;
+    shade_stage(sv, sv.perlin_tables, h, rd, may_reflect, so);
+    out.color = so.color;
+    out.refl = so.refl;
+    out.spawn = so.spawn;
+    out.child_o = so.child_o;
+    out.child_d = so.child_d;
+    out.shape = h.shape;
+    out.tri = h.tri;
+    out.shadow_rays = so.shadow_rays;
 }
 
 // Fold of one level: directLighting + (child * reflectance) with clamping Color ops (Raytracer.cpp:283, 286)
@@ -751,11 +871,9 @@ RT_HD Col raycast(const SceneView &sv, V3 o, V3 d, uint32_t max_recursion, KdSta
     return c;
 }
 
-// DebugRaycaster::Raycast (Raytracer.cpp:317-351); mode 0 Normal, 1 Color
-RT_HD Col debug_raycast(const SceneView &sv, V3 o, V3 d, int mode, KdStack &st, int32_t *shape, int32_t *tri) {
-    Hit h = cast_ray(sv, o, d, st, false, nullptr);
-    if (shape) *shape = h.shape;
-    if (tri) *tri = h.tri;
+// DebugRaycaster::Raycast (Raytracer.cpp:317-351); mode 0 Normal, 1 Color: shading half (the query half is a
+// closest-hit cast_ray)
+RT_HD Col debug_shade(const SceneView &sv, const uint8_t *tabs, const HitRec &h, V3 d, int mode) {
     if (mode == 0) {
         if (h.shape >= 0) return mkc((h.normal.x + 1) / 2, (h.normal.y + 1) / 2, 1 - (h.normal.z + 1) / 2);
         return Col{0, 0, 0};
@@ -763,10 +881,22 @@ RT_HD Col debug_raycast(const SceneView &sv, V3 o, V3 d, int mode, KdStack &st, 
     if (h.shape >= 0) {
         Col albedo;
         double a;
-        material_eval(sv, sv.shapes[h.shape].material, h.local, albedo, a);
+        material_eval(sv, tabs, sv.shapes[h.shape].material, h.local, albedo, a);
         return albedo;
     }
-    return background_color(sv, d);
+    return background_color(sv, tabs, d);
+}
+RT_HD Col debug_raycast(const SceneView &sv, V3 o, V3 d, int mode, KdStack &st, int32_t *shape, int32_t *tri) {
+    Hit c = cast_ray(sv, o, d, st, false, nullptr);
+    if (shape) *shape = c.shape;
+    if (tri) *tri = c.tri;
+    HitRec h;
+    h.shape = c.shape;
+    h.tri = c.tri;
+    h.shadow_mask = 0;
+    h.local = c.local;
+    h.normal = c.normal;
+    return debug_shade(sv, sv.perlin_tables, h, d, mode);
 }
 
 // ----------------------------------------------------------------------------- ray generation (R1)

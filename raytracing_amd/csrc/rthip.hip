@@ -1,11 +1,12 @@
 // rthip.hip — HIP kernels (gfx950 / CDNA4) + C-ABI of the Raycast hot path.  See include/rthip.h.
 //
 // Frame pipeline (wavefront style, one ray per lane, 64-lane waves):
-//   k_bounce level 0 : ray generation fused with closest hit + shading of the primary rays;
-//                      reflected rays are compacted into the level-1 queue with a wave ballot /
-//                      prefix count and ONE atomic per wave.
-//   k_bounce level k : same over the compacted level-k queue (count read from device memory, so
-//                      the host never synchronises between levels).
+//   k_trace level k  : every scene query of the level — closest hit (level 0 generates its rays)
+//                      and one shadow query per light; traversal code only, hit records out.
+//   k_shade level k  : material / noise / background, Lambert terms, reflected rays compacted
+//                      into the level-(k+1) queue with a wave ballot + prefix popcount and ONE
+//                      atomic per workgroup.  Level counts are read from device memory, so the
+//                      host never synchronises between levels.
 //   k_fold level k   : C_{k-1} = direct_{k-1} (+) C_k (x) refl_{k-1}  (clamping Color algebra forbids a
 //                      forward throughput product), back to front.
 //   k_resolve        : level-0 colours -> 0xAABBGGRR pixels (and the 3x3 SSAA sum).
@@ -64,6 +65,14 @@ struct DevBuf {
 };
 
 static const uint32_t kBlock = 256;           // 4 waves per workgroup
+// minimum waves per SIMD the register allocator must leave room for (the kernels are
+// bound by dependent fp64 chains, so resident waves matter more than a few spilled values)
+#ifndef RT_TRACE_OCC
+#define RT_TRACE_OCC 4
+#endif
+#ifndef RT_SHADE_OCC
+#define RT_SHADE_OCC 4
+#endif
 static const uint32_t kMaxGridLevel = 4096;   // queue levels: grid-stride over a bounded grid
 enum { ST_PRIMARY = 0, ST_SHADOW, ST_REFLECT, ST_KD_NODES, ST_KD_TRIS, ST_KD_LEAVES, ST_KD_POPS, ST_SHAPES, ST_MESH_HITS, ST_COUNT };
 
@@ -87,12 +96,18 @@ struct Work {
     uint32_t *counts;       // [levels+1]   : rays per level
     unsigned long long *stats;  // [ST_COUNT]
     int32_t *id_shape, *id_tri; // [n_pix_slots] primary-hit ids (optional)
+    int32_t *hit_shape;         // [N] per ray of the current level: shape ordinal, -1 miss, -2 no ray
+    uint32_t *hit_mask;         // [N] shadow mask
+    double *hit;                // [6][N] local point, normal
+    uint32_t *redo;             // [N] rays of the current level that must be re-traced by the full kernel
+    uint32_t *redo_count;       // [levels] one counter per level (zeroed with `counts`)
     uint32_t N;
 };
 
 __device__ __forceinline__ double *rec_ptr(const Work &w, uint32_t level, uint32_t comp) {
     return w.rec + ((size_t)level * 4 + comp) * w.N;
 }
+__device__ __forceinline__ double *hit_ptr(const Work &w, uint32_t comp) { return w.hit + (size_t)comp * w.N; }
 __device__ __forceinline__ double *ray_ptr(const Work &w, uint32_t level, uint32_t comp) {
     return w.rays + ((size_t)(level & 1) * 6 + comp) * w.N;
 }
@@ -120,100 +135,101 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 }
 
 // ============================================================================ kernels
-extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];
+extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[];
 
-__global__ __launch_bounds__(kBlock) void k_bounce(SceneView sv, FrameParams fp, Work w, uint32_t level,
-                                                   uint32_t stack_cap) {
+// Stage 1 of a level: every scene query of the level.
+// Level 0 generates its rays (R1).  Output: one HitRec per ray (SoA) + the ray direction.
+// FAST = true is the hot instantiation: BVH only; rays that meet a degenerate (ray, mesh) pair are
+// appended to the redo list and re-traced by the FAST = false instantiation (which also serves
+// accel = 1, the reference kd-tree everywhere).  REDO = true: `n` and the ray indices come from the
+// redo list.
+template <bool FAST, bool REDO>
+__global__ __launch_bounds__(kBlock, RT_TRACE_OCC) void k_trace(SceneView sv, FrameParams fp, Work w, uint32_t level,
+                                                                 uint32_t stack_cap) {
     KdStack st;
-    st.base = lds_stack + threadIdx.x;
+    st.base = lds_dyn + threadIdx.x;
     st.stride = kBlock;
     st.cap = stack_cap;
     st.n = 0;
-    const uint32_t n = (level == 0) ? fp.N0 : w.counts[level];
-    const uint32_t lane = threadIdx.x & 63u;
-    uint32_t shadow_total = 0, spawn_total = 0;
+    const uint32_t n = REDO ? w.redo_count[0] : ((level == 0) ? fp.N0 : w.counts[level]);
     KdCounters kc = {0, 0, 0, 0, 0, 0};
     KdCounters *kcp = fp.count_kd ? &kc : nullptr;
     for (uint32_t base = blockIdx.x * kBlock; base < n; base += gridDim.x * kBlock) {
-        uint32_t i = base + threadIdx.x;
-        bool active = i < n;
-        V3 o = mk(0, 0, 0), d = mk(0, 0, 1);
+        uint32_t j = base + threadIdx.x;
+        if (j >= n) continue;
+        const uint32_t i = REDO ? w.redo[j] : j;
+        V3 o, d;
         uint32_t pix_slot = 0;
-        if (active) {
-            if (level == 0) {
-                uint32_t s = i / fp.n_pix_slots;  // SSAA sub-sample (0 when aa is off)
-                pix_slot = i - s * fp.n_pix_slots;
-                uint32_t x, y;
-                active = slot_to_pixel(fp, pix_slot, x, y);
-                if (active) {
-                    double fx = (double)x, fy = (double)y;
-                    if (fp.aa) {  // Raytracer.cpp:134-138: dx outer, dy inner, offsets +-0.5
-                        int dx = (int)(s / 3) - 1, dy = (int)(s % 3) - 1;
-                        fx = (double)((float)x + (float)dx * .5f);
-                        fy = (double)((float)(int)y + (float)dy * .5f);
-                    }
-                    screen_ray(fp.cam, fp.W, fp.H, fx, fy, o, d);
-                }
-            } else {
-                o = mk(ray_ptr(w, level, 0)[i], ray_ptr(w, level, 1)[i], ray_ptr(w, level, 2)[i]);
-                d = mk(ray_ptr(w, level, 3)[i], ray_ptr(w, level, 4)[i], ray_ptr(w, level, 5)[i]);
+        if (level == 0) {
+            uint32_t s = i / fp.n_pix_slots;  // SSAA sub-sample (0 when aa is off)
+            pix_slot = i - s * fp.n_pix_slots;
+            uint32_t x, y;
+            if (!slot_to_pixel(fp, pix_slot, x, y)) {
+                w.hit_shape[i] = -2;  // slot outside the image
+                continue;
+            }
+            double fx = (double)x, fy = (double)y;
+            if (fp.aa) {  // Raytracer.cpp:134-138: dx outer, dy inner, offsets +-0.5
+                int dx = (int)(s / 3) - 1, dy = (int)(s % 3) - 1;
+                fx = (double)((float)x + (float)dx * .5f);
+                fy = (double)((float)(int)y + (float)dy * .5f);
+            }
+            screen_ray(fp.cam, fp.W, fp.H, fx, fy, o, d);
+            if (!REDO) {
+                ray_ptr(w, 0, 3)[i] = d.x;  // the shade stage needs the direction (background, reflection)
+                ray_ptr(w, 0, 4)[i] = d.y;
+                ray_ptr(w, 0, 5)[i] = d.z;
+            }
+        } else {
+            o = mk(ray_ptr(w, level, 0)[i], ray_ptr(w, level, 1)[i], ray_ptr(w, level, 2)[i]);
+            d = mk(ray_ptr(w, level, 3)[i], ray_ptr(w, level, 4)[i], ray_ptr(w, level, 5)[i]);
+        }
+        HitRec h;
+        bool done = true;
+        if (fp.renderer == RTHIP_RENDER_RAYTRACER) {
+            done = trace_stage<FAST>(sv, o, d, st, h, kcp);
+        } else {  // DebugRaycaster: one closest-hit query, no shadow rays
+            bool redo = false;
+            h.shadow_mask = 0;
+            h.local = h.normal = mk(0, 0, 0);
+            h.shape = cast_ray_id<FAST>(sv, o, d, st, false, h.tri, redo, kcp);
+            done = !(FAST && redo);
+            if (done && h.shape >= 0) {
+                Hit c;
+                hit_details(sv, o, d, h.shape, h.tri, c, kcp);
+                h.local = c.local;
+                h.normal = c.normal;
             }
         }
-        Bounce b;
-        b.spawn = false;
-        b.shadow_rays = 0;
-        if (active) {
-            if (fp.renderer == RTHIP_RENDER_RAYTRACER) {
-                bounce(sv, o, d, level < fp.max_rec, st, b, kcp);
-            } else {
-                b.color = debug_raycast(sv, o, d, fp.renderer - 1, st, &b.shape, &b.tri);
-                b.refl = 0.0;
-            }
-            rec_ptr(w, level, 0)[i] = b.color.r;
-            rec_ptr(w, level, 1)[i] = b.color.g;
-            rec_ptr(w, level, 2)[i] = b.color.b;
-            rec_ptr(w, level, 3)[i] = b.refl;
-            // primary-hit ids come from the un-offset pixel-centre ray (sub-sample 4 of the 3x3 SSAA grid)
-            if (level == 0 && w.id_shape && i / fp.n_pix_slots == (fp.aa ? 4u : 0u)) {
-                w.id_shape[pix_slot] = b.shape;
-                w.id_tri[pix_slot] = b.tri;
-            }
+        if (FAST && !done) {  // rare: hand the ray to the full instantiation
+            w.redo[atomicAdd(&w.redo_count[0], 1u)] = i;
+            continue;
         }
-        // compaction of the reflected rays: ballot + prefix count, one atomic per wave
-        unsigned long long mask = __ballot(b.spawn);
-        if (mask) {
-            uint32_t cnt = (uint32_t)__popcll(mask);
-            uint32_t wbase = 0;
-            if (lane == 0) wbase = atomicAdd(&w.counts[level + 1], cnt);
-            wbase = __shfl(wbase, 0, 64);
-            if (b.spawn) {
-                uint32_t j = wbase + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-                ray_ptr(w, level + 1, 0)[j] = b.child_o.x;
-                ray_ptr(w, level + 1, 1)[j] = b.child_o.y;
-                ray_ptr(w, level + 1, 2)[j] = b.child_o.z;
-                ray_ptr(w, level + 1, 3)[j] = b.child_d.x;
-                ray_ptr(w, level + 1, 4)[j] = b.child_d.y;
-                ray_ptr(w, level + 1, 5)[j] = b.child_d.z;
-                w.parent[(size_t)(level + 1) * w.N + j] = i;
-            }
-            spawn_total += b.spawn ? 1u : 0u;
+        w.hit_shape[i] = h.shape;
+        if (h.shape >= 0) {
+            w.hit_mask[i] = h.shadow_mask;
+            hit_ptr(w, 0)[i] = h.local.x;
+            hit_ptr(w, 1)[i] = h.local.y;
+            hit_ptr(w, 2)[i] = h.local.z;
+            hit_ptr(w, 3)[i] = h.normal.x;
+            hit_ptr(w, 4)[i] = h.normal.y;
+            hit_ptr(w, 5)[i] = h.normal.z;
         }
-        shadow_total += b.shadow_rays;
+        // primary-hit ids come from the un-offset pixel-centre ray (sub-sample 4 of the 3x3 SSAA grid)
+        if (level == 0 && w.id_shape && i / fp.n_pix_slots == (fp.aa ? 4u : 0u)) {
+            w.id_shape[pix_slot] = h.shape;
+            w.id_tri[pix_slot] = h.tri;
+        }
     }
-    shadow_total = wave_sum(shadow_total);
-    spawn_total = wave_sum(spawn_total);
     if (fp.count_kd) {
+        const uint32_t lane = threadIdx.x & 63u;
         kc.nodes = wave_sum(kc.nodes);
         kc.tris = wave_sum(kc.tris);
         kc.leaves = wave_sum(kc.leaves);
         kc.pops = wave_sum(kc.pops);
         kc.shapes = wave_sum(kc.shapes);
         kc.mesh_hits = wave_sum(kc.mesh_hits);
-    }
-    if (lane == 0) {
-        if (shadow_total) atomicAdd(&w.stats[ST_SHADOW], (unsigned long long)shadow_total);
-        if (spawn_total) atomicAdd(&w.stats[ST_REFLECT], (unsigned long long)spawn_total);
-        if (fp.count_kd) {
+        if (lane == 0) {
             atomicAdd(&w.stats[ST_KD_NODES], (unsigned long long)kc.nodes);
             atomicAdd(&w.stats[ST_KD_TRIS], (unsigned long long)kc.tris);
             atomicAdd(&w.stats[ST_KD_LEAVES], (unsigned long long)kc.leaves);
@@ -221,6 +237,86 @@ __global__ __launch_bounds__(kBlock) void k_bounce(SceneView sv, FrameParams fp,
             atomicAdd(&w.stats[ST_SHAPES], (unsigned long long)kc.shapes);
             atomicAdd(&w.stats[ST_MESH_HITS], (unsigned long long)kc.mesh_hits);
         }
+    }
+}
+
+// Stage 2 of a level: material / noise / background, Lambert terms with the shadow mask, and the
+// reflected rays, compacted into the next level's queue: wave ballot + prefix popcount, the four
+// waves of a workgroup combined through LDS so that ONE returning atomic per workgroup reserves the
+// queue range (32 K per-wave atomics on one word cost more than the shading itself).
+// The Perlin tables (256 B each) are staged in LDS: their chained lookups are the latency chain of
+// every sky / marble sample.
+__global__ __launch_bounds__(kBlock, RT_SHADE_OCC) void k_shade(SceneView sv, FrameParams fp, Work w, uint32_t level, uint32_t n_tables) {
+    uint8_t *tabs = reinterpret_cast<uint8_t *>(lds_dyn);
+    __shared__ uint32_t wave_cnt[kBlock / 64];
+    __shared__ uint32_t block_base;
+    {
+        const uint32_t words = n_tables * 64;
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(sv.perlin_tables);
+        for (uint32_t k = threadIdx.x; k < words; k += kBlock) lds_dyn[k] = src[k];
+        __syncthreads();
+    }
+    const uint32_t n = (level == 0) ? fp.N0 : w.counts[level];
+    const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
+    uint32_t shadow_total = 0, spawn_total = 0;
+    for (uint32_t base = blockIdx.x * kBlock; base < n; base += gridDim.x * kBlock) {
+        uint32_t i = base + threadIdx.x;
+        ShadeOut so;
+        so.spawn = false;
+        so.shadow_rays = 0;
+        int32_t shape = i < n ? w.hit_shape[i] : -2;
+        if (shape > -2) {
+            HitRec h;
+            h.shape = shape;
+            h.tri = -1;
+            h.shadow_mask = 0;
+            h.local = h.normal = mk(0, 0, 0);
+            V3 d = mk(ray_ptr(w, level, 3)[i], ray_ptr(w, level, 4)[i], ray_ptr(w, level, 5)[i]);
+            if (shape >= 0) {
+                h.shadow_mask = w.hit_mask[i];
+                h.local = mk(hit_ptr(w, 0)[i], hit_ptr(w, 1)[i], hit_ptr(w, 2)[i]);
+                h.normal = mk(hit_ptr(w, 3)[i], hit_ptr(w, 4)[i], hit_ptr(w, 5)[i]);
+            }
+            if (fp.renderer == RTHIP_RENDER_RAYTRACER) {
+                shade_stage(sv, tabs, h, d, level < fp.max_rec, so);
+            } else {
+                so.color = debug_shade(sv, tabs, h, d, fp.renderer - 1);
+                so.refl = 0.0;
+            }
+            rec_ptr(w, level, 0)[i] = so.color.r;
+            rec_ptr(w, level, 1)[i] = so.color.g;
+            rec_ptr(w, level, 2)[i] = so.color.b;
+            rec_ptr(w, level, 3)[i] = so.refl;
+        }
+        // compaction of the reflected rays
+        unsigned long long mask = __ballot(so.spawn);
+        if (lane == 0) wave_cnt[wid] = (uint32_t)__popcll(mask);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t total = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+            block_base = total ? atomicAdd(&w.counts[level + 1], total) : 0u;
+        }
+        __syncthreads();
+        if (so.spawn) {
+            uint32_t j = block_base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+            for (uint32_t k = 0; k < wid; k++) j += wave_cnt[k];
+            ray_ptr(w, level + 1, 0)[j] = so.child_o.x;
+            ray_ptr(w, level + 1, 1)[j] = so.child_o.y;
+            ray_ptr(w, level + 1, 2)[j] = so.child_o.z;
+            ray_ptr(w, level + 1, 3)[j] = so.child_d.x;
+            ray_ptr(w, level + 1, 4)[j] = so.child_d.y;
+            ray_ptr(w, level + 1, 5)[j] = so.child_d.z;
+            w.parent[(size_t)(level + 1) * w.N + j] = i;
+            spawn_total++;
+        }
+        shadow_total += so.shadow_rays;
+        __syncthreads();  // wave_cnt / block_base are reused by the next chunk
+    }
+    shadow_total = wave_sum(shadow_total);
+    spawn_total = wave_sum(spawn_total);
+    if (lane == 0) {
+        if (shadow_total) atomicAdd(&w.stats[ST_SHADOW], (unsigned long long)shadow_total);
+        if (spawn_total) atomicAdd(&w.stats[ST_REFLECT], (unsigned long long)spawn_total);
     }
 }
 
@@ -280,7 +376,7 @@ __global__ __launch_bounds__(kBlock) void k_assemble(FrameParams fp, const uint3
 __global__ __launch_bounds__(kBlock) void k_probe_cast(SceneView sv, uint32_t n, const double *o, const double *d,
                                                        int32_t *hit, double *point, double *local, double *normal,
                                                        int32_t *shape, int32_t *tri, uint32_t stack_cap) {
-    KdStack st{lds_stack + threadIdx.x, kBlock, stack_cap, 0};
+    KdStack st{lds_dyn + threadIdx.x, kBlock, stack_cap, 0};
     uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     Hit h = cast_ray(sv, mk(o[3 * i], o[3 * i + 1], o[3 * i + 2]), mk(d[3 * i], d[3 * i + 1], d[3 * i + 2]), st, false, nullptr);
@@ -294,7 +390,7 @@ __global__ __launch_bounds__(kBlock) void k_probe_cast(SceneView sv, uint32_t n,
 __global__ __launch_bounds__(kBlock) void k_probe_noise(SceneView sv, int32_t noise, uint32_t n, const double *p, double *out) {
     uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
-    out[i] = noise_sample(sv, noise, mk(p[3 * i], p[3 * i + 1], p[3 * i + 2]));
+    out[i] = noise_sample(sv, sv.perlin_tables, noise, mk(p[3 * i], p[3 * i + 1], p[3 * i + 2]));
 }
 __global__ __launch_bounds__(kBlock) void k_probe_material(SceneView sv, int32_t mat, uint32_t n, const double *p,
                                                            double *color, double *absorptance) {
@@ -302,19 +398,19 @@ __global__ __launch_bounds__(kBlock) void k_probe_material(SceneView sv, int32_t
     if (i >= n) return;
     Col c;
     double a;
-    material_eval(sv, mat, mk(p[3 * i], p[3 * i + 1], p[3 * i + 2]), c, a);
+    material_eval(sv, sv.perlin_tables, mat, mk(p[3 * i], p[3 * i + 1], p[3 * i + 2]), c, a);
     color[3 * i] = c.r; color[3 * i + 1] = c.g; color[3 * i + 2] = c.b;
     absorptance[i] = a;
 }
 __global__ __launch_bounds__(kBlock) void k_probe_background(SceneView sv, uint32_t n, const double *d, double *color) {
     uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
-    Col c = background_color(sv, mk(d[3 * i], d[3 * i + 1], d[3 * i + 2]));
+    Col c = background_color(sv, sv.perlin_tables, mk(d[3 * i], d[3 * i + 1], d[3 * i + 2]));
     color[3 * i] = c.r; color[3 * i + 1] = c.g; color[3 * i + 2] = c.b;
 }
 __global__ __launch_bounds__(kBlock) void k_probe_raycast(SceneView sv, uint32_t max_rec, uint32_t n, const double *o,
                                                           const double *d, double *color, uint32_t stack_cap) {
-    KdStack st{lds_stack + threadIdx.x, kBlock, stack_cap, 0};
+    KdStack st{lds_dyn + threadIdx.x, kBlock, stack_cap, 0};
     uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     Col c = raycast(sv, mk(o[3 * i], o[3 * i + 1], o[3 * i + 2]), mk(d[3 * i], d[3 * i + 1], d[3 * i + 2]), max_rec, st, nullptr);
@@ -352,7 +448,9 @@ struct rthip_ctx {
     bool has_scene = false;
     uint32_t stack_cap = 1;
     // frame workspace
-    DevBuf rec, parent, rays, counts, stats, ids, pixels_tmp, ids_out, probe[8];
+    DevBuf rec, parent, rays, counts, stats, ids, pixels_tmp, ids_out, hits, hit_ids, redo, probe[8];
+    uint32_t n_tables = 0;
+    bool has_meshes = false;
     std::atomic<int> interrupt{0};
     std::atomic<float> progress{0.f};
     rthip_stats last{};
@@ -402,7 +500,7 @@ int rthip_destroy(rthip_ctx *c) {
     (void)hipStreamSynchronize(c->stream);
     DevBuf *all[] = {&c->shapes, &c->meshes, &c->kd_nodes, &c->kd_bounds, &c->kd_refs, &c->tris, &c->tri_normals,
                      &c->materials, &c->noises, &c->perlin, &c->worley, &c->lights, &c->rec, &c->parent, &c->rays,
-                     &c->counts, &c->stats, &c->ids, &c->pixels_tmp, &c->ids_out, &c->bvh_nodes, &c->bvh_tris, &c->bvh_index, &c->kd_planes};
+                     &c->counts, &c->stats, &c->ids, &c->pixels_tmp, &c->ids_out, &c->bvh_nodes, &c->bvh_tris, &c->bvh_index, &c->kd_planes, &c->hits, &c->hit_ids, &c->redo};
     for (DevBuf *b : all) b->release();
     for (DevBuf &b : c->probe) b.release();
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
@@ -521,6 +619,8 @@ static int validate_scene(const rthip_scene_desc *s, uint32_t *max_depth, uint32
         if (sh.material < 0 || (uint32_t)sh.material >= s->n_materials) BAD("shape %u: material %d out of range", i, sh.material);
         if (sh.type == RTHIP_SHAPE_MESH && (sh.mesh < 0 || (uint32_t)sh.mesh >= s->n_meshes)) BAD("shape %u: mesh %d out of range", i, sh.mesh);
     }
+    if (s->n_lights > 32) return fail(RTHIP_E_UNSUPPORTED, "rthip_upload_scene: %u lights (the shadow mask holds 32)", s->n_lights);
+    if (s->n_perlin_tables > 128) return fail(RTHIP_E_UNSUPPORTED, "rthip_upload_scene: %u Perlin tables (LDS staging holds 128)", s->n_perlin_tables);
     for (uint32_t i = 0; i < s->n_lights; i++)
         if (s->lights[i].type < RTHIP_LIGHT_DIRECTIONAL || s->lights[i].type > RTHIP_LIGHT_POINT) BAD("light %u: bad type", i);
     const rthip_background &bg = s->background;
@@ -584,6 +684,8 @@ int rthip_upload_scene(rthip_ctx *c, const rthip_scene_desc *s) {
     v.worley_points = (const double *)c->worley.p;
     v.lights = (const rthip_light *)c->lights.p;
     v.n_lights = s->n_lights;
+    c->n_tables = s->n_perlin_tables;
+    c->has_meshes = s->n_meshes > 0;
     v.bg = s->background;
     c->stack_cap_kd = max_depth + 2;
     c->stack_cap_bvh = max_bvh_depth + 2;
@@ -649,9 +751,12 @@ static int render_frame(rthip_ctx *c, const rthip_camera *cam, const rthip_param
     if (c->rec.ensure(sizeof(double) * 4 * N * levels)) return RTHIP_E_HIP;
     if (c->parent.ensure(sizeof(uint32_t) * N * levels)) return RTHIP_E_HIP;
     if (c->rays.ensure(sizeof(double) * 12 * N)) return RTHIP_E_HIP;
-    if (c->counts.ensure(sizeof(uint32_t) * (RTHIP_MAX_RECURSION + 3))) return RTHIP_E_HIP;
+    if (c->counts.ensure(sizeof(uint32_t) * 2 * (RTHIP_MAX_RECURSION + 3))) return RTHIP_E_HIP;
     if (c->stats.ensure(sizeof(unsigned long long) * ST_COUNT)) return RTHIP_E_HIP;
     if (c->ids.ensure(sizeof(int32_t) * 2 * (size_t)tiles_per_chunk * per_tile)) return RTHIP_E_HIP;
+    if (c->hits.ensure(sizeof(double) * 6 * N)) return RTHIP_E_HIP;
+    if (c->hit_ids.ensure(sizeof(uint32_t) * 2 * N)) return RTHIP_E_HIP;
+    if (c->redo.ensure(sizeof(uint32_t) * N)) return RTHIP_E_HIP;
     Work w;
     w.rec = (double *)c->rec.p;
     w.parent = (uint32_t *)c->parent.p;
@@ -660,6 +765,10 @@ static int render_frame(rthip_ctx *c, const rthip_camera *cam, const rthip_param
     w.stats = (unsigned long long *)c->stats.p;
     w.id_shape = (d_shape || d_tri) ? (int32_t *)c->ids.p : nullptr;
     w.id_tri = w.id_shape ? w.id_shape + (size_t)tiles_per_chunk * per_tile : nullptr;
+    w.hit = (double *)c->hits.p;
+    w.hit_shape = (int32_t *)c->hit_ids.p;
+    w.hit_mask = (uint32_t *)c->hit_ids.p + N;
+    w.redo = (uint32_t *)c->redo.p;
     w.N = (uint32_t)N;
 
     c->sv.accel = p->accel;
@@ -667,7 +776,12 @@ static int render_frame(rthip_ctx *c, const rthip_camera *cam, const rthip_param
     const size_t lds_bytes = (size_t)c->stack_cap * kBlock * sizeof(uint32_t);
     if (lds_bytes > 160 * 1024) return fail(RTHIP_E_UNSUPPORTED, "kd stack of %u entries does not fit LDS", c->stack_cap);
     if (lds_bytes > 64 * 1024)
-        HIP_TRY(hipFuncSetAttribute((const void *)k_bounce, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    {
+        HIP_TRY(hipFuncSetAttribute((const void *)k_trace<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        HIP_TRY(hipFuncSetAttribute((const void *)k_trace<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        HIP_TRY(hipFuncSetAttribute((const void *)k_trace<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    }
+    const size_t lds_tables = (size_t)c->n_tables * 256;
 
     HIP_TRY(hipMemsetAsync(w.stats, 0, sizeof(unsigned long long) * ST_COUNT, c->stream));
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
@@ -689,7 +803,7 @@ static int render_frame(rthip_ctx *c, const rthip_camera *cam, const rthip_param
         fp.q0 = q0;
         fp.n_pix_slots = nq * per_tile;
         fp.N0 = fp.n_pix_slots * spp;
-        HIP_TRY(hipMemsetAsync(w.counts, 0, sizeof(uint32_t) * (RTHIP_MAX_RECURSION + 3), c->stream));
+        HIP_TRY(hipMemsetAsync(w.counts, 0, sizeof(uint32_t) * 2 * (RTHIP_MAX_RECURSION + 3), c->stream));
         for (uint32_t level = 0; level < levels; level++) {
             uint32_t grid = (fp.N0 + kBlock - 1) / kBlock;
             if (level > 0 && grid > kMaxGridLevel) grid = kMaxGridLevel;
@@ -698,8 +812,17 @@ static int render_frame(rthip_ctx *c, const rthip_camera *cam, const rthip_param
                 if (get_event(&ea) || get_event(&eb)) return RTHIP_E_HIP;
                 HIP_TRY(hipEventRecord(ea, c->stream));
             }
-            hipLaunchKernelGGL(k_bounce, dim3(grid), dim3(kBlock), lds_bytes, c->stream, c->sv, fp, w, level, c->stack_cap);
-            if (c->profile_launches) HIP_TRY(hipEventRecord(eb, c->stream));
+            w.redo_count = w.counts + (RTHIP_MAX_RECURSION + 3) + level;
+            if (p->accel == 0) {
+                hipLaunchKernelGGL((k_trace<true, false>), dim3(grid), dim3(kBlock), lds_bytes, c->stream, c->sv, fp, w, level, c->stack_cap);
+                if (c->profile_launches) HIP_TRY(hipEventRecord(eb, c->stream));
+                if (c->has_meshes)  // re-trace of the (rare) rays lying exactly in a kd split plane
+                    hipLaunchKernelGGL((k_trace<false, true>), dim3(64), dim3(kBlock), lds_bytes, c->stream, c->sv, fp, w, level, c->stack_cap);
+            } else {
+                hipLaunchKernelGGL((k_trace<false, false>), dim3(grid), dim3(kBlock), lds_bytes, c->stream, c->sv, fp, w, level, c->stack_cap);
+                if (c->profile_launches) HIP_TRY(hipEventRecord(eb, c->stream));
+            }
+            hipLaunchKernelGGL(k_shade, dim3(grid), dim3(kBlock), lds_tables, c->stream, c->sv, fp, w, level, c->n_tables);
         }
         for (uint32_t level = levels - 1; level >= 1; level--) {
             uint32_t grid = (fp.N0 + kBlock - 1) / kBlock;

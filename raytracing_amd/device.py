@@ -7,7 +7,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-RTHIP_SO = os.path.join(_HERE, "lib", "librthip.so")
+RTHIP_SO = os.environ.get("RTHIP_SO") or os.path.join(_HERE, "lib", "librthip.so")  # env override: A/B builds in perf scripts
 
 c_dp = C.POINTER(C.c_double)
 c_i32p = C.POINTER(C.c_int32)

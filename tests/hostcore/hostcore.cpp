@@ -101,14 +101,14 @@ int hc_cast(const rthip_scene_desc *scene, uint32_t n, const double *o, const do
 }
 int hc_noise(const rthip_scene_desc *scene, int32_t noise, uint32_t n, const double *p, double *out) {
     SceneView sv = view_of(scene);
-    for (uint32_t i = 0; i < n; i++) out[i] = noise_sample(sv, noise, mk(p[3 * i], p[3 * i + 1], p[3 * i + 2]));
+    for (uint32_t i = 0; i < n; i++) out[i] = noise_sample(sv, sv.perlin_tables, noise, mk(p[3 * i], p[3 * i + 1], p[3 * i + 2]));
     return 0;
 }
 int hc_material(const rthip_scene_desc *scene, int32_t mat, uint32_t n, const double *p, double *color, double *absorptance) {
     SceneView sv = view_of(scene);
     for (uint32_t i = 0; i < n; i++) {
         Col c; double a;
-        material_eval(sv, mat, mk(p[3 * i], p[3 * i + 1], p[3 * i + 2]), c, a);
+        material_eval(sv, sv.perlin_tables, mat, mk(p[3 * i], p[3 * i + 1], p[3 * i + 2]), c, a);
         color[3 * i] = c.r; color[3 * i + 1] = c.g; color[3 * i + 2] = c.b; absorptance[i] = a;
     }
     return 0;
@@ -116,7 +116,7 @@ int hc_material(const rthip_scene_desc *scene, int32_t mat, uint32_t n, const do
 int hc_background(const rthip_scene_desc *scene, uint32_t n, const double *d, double *color) {
     SceneView sv = view_of(scene);
     for (uint32_t i = 0; i < n; i++) {
-        Col c = background_color(sv, mk(d[3 * i], d[3 * i + 1], d[3 * i + 2]));
+        Col c = background_color(sv, sv.perlin_tables, mk(d[3 * i], d[3 * i + 1], d[3 * i + 2]));
         color[3 * i] = c.r; color[3 * i + 1] = c.g; color[3 * i + 2] = c.b;
     }
     return 0;
