@@ -55,6 +55,11 @@ typedef struct {
     double fwd[12];      /* local -> world */
     double nrm[12];      /* normal transform */
     double plane_n[4];   /* Plane::Normal (un-normalised, Scene.h:159); [3] unused */
+    /* filled by rthip_upload_scene (callers leave them 0): bounds on E = fwd*inv - I, the round-trip
+     * error of the two independently computed matrices (rotations come from float cosf/sinf,
+     * Common.cpp:401-423): rt_lin >= ||E_3x3||_inf, rt_t >= |E translation|_inf.  They bound how far
+     * the reference's self-intersection test (Scene.cpp:196-200) can reach along a shadow ray. */
+    double rt_lin, rt_t;
 } rthip_shape;
 
 /* kd-tree node, 16 bytes.  Nodes of one mesh are stored in pre-order; the left child of an
@@ -228,6 +233,16 @@ typedef struct {
     uint64_t kd_pops;            /* pending subtrees resumed (48 B of bounds each) */
     uint64_t shape_tests;        /* shape-table entries tested (world->local transform fetch) */
     uint64_t mesh_hits;          /* mesh hits whose vertex normals were fetched (72 B) */
+    uint64_t kd_max_nodes_ray;   /* most node records any single ray (all its queries) fetched (tail-latency diagnostic) */
+    /* divergence diagnostics: BVH interior steps / triangle-test iterations executed per WAVE (a wave
+     * executes a step when any of its lanes does): the largest of any wave over the frame (summed over
+     * the grid-stride iterations of that wave), and the totals */
+    uint64_t wave_steps_max, wave_tris_max, wave_steps, wave_tris;
+    uint64_t wave_cycles_max;    /* longest-lived trace wave of the frame, shader clock cycles */
+    /* per recursion level of the last chunk: rays in the level's queue, and (RTHIP_PROFILE_LAUNCHES=1)
+     * the duration of the level's trace kernel */
+    uint32_t level_rays[RTHIP_MAX_RECURSION + 1];
+    float level_ms_trace[RTHIP_MAX_RECURSION + 1];
 } rthip_stats;
 
 /* ---- lifecycle ---- */

@@ -55,30 +55,90 @@ struct SceneView {
     rthip_background bg;
 };
 
+// Shape and light records are indexed by wave-uniform loop counters.  On the device they are read
+// through the constant address space (same memory, but the loads are invariant and therefore scalar:
+// one s_load per wave, the matrices land in SGPRs instead of 24 VGPRs per lane).
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef const __attribute__((address_space(4))) rthip_shape rt_uniform_shape;
+typedef const __attribute__((address_space(4))) rthip_light rt_uniform_light;
+typedef const __attribute__((address_space(4))) rthip_mesh rt_uniform_mesh;
+__device__ __forceinline__ rthip_mesh rt_load_mesh(const rthip_mesh *p) {
+    rthip_mesh m;
+    __builtin_memcpy(&m, (rt_uniform_mesh *)p, sizeof m);
+    return m;
+}
+__device__ __forceinline__ rt_uniform_shape *rt_uniform_cast(const rthip_shape *p) { return (rt_uniform_shape *)p; }
+__device__ __forceinline__ rt_uniform_light *rt_uniform_cast(const rthip_light *p) { return (rt_uniform_light *)p; }
+#else
+typedef const rthip_shape rt_uniform_shape;
+typedef const rthip_light rt_uniform_light;
+inline rt_uniform_shape *rt_uniform_cast(const rthip_shape *p) { return p; }
+inline rt_uniform_light *rt_uniform_cast(const rthip_light *p) { return p; }
+inline rthip_mesh rt_load_mesh(const rthip_mesh *p) { return *p; }
+#endif
+
 // Traversal stack: `stride` lets the device interleave the lanes of a workgroup in LDS
-// (entry k of lane t lives at base[k*stride], base already offset by t).
+// (entry k of lane t lives at base[k*stride], base already offset by t).  The BVH walk also keeps
+// the entry parameter of every pending subtree (tbase, same indexing; may be null = no culling on
+// pop).  A push beyond `cap` sets `overflow`: the caller re-runs the ray where the stack is full-depth.
 struct KdStack {
     uint32_t *base;
     uint32_t stride;
     uint32_t cap;
     uint32_t n;
+    float *tbase;
+    bool overflow;
     RT_HD void clear() { n = 0; }
     RT_HD bool empty() const { return n == 0; }
     RT_HD void push(uint32_t v) {
         if (n < cap) {
             base[n * stride] = v;
             n++;
+        } else {
+            overflow = true;
         }
     }
     RT_HD uint32_t pop() {
         n--;
         return base[n * stride];
     }
+    RT_HD void push_t(uint32_t v, float t) {
+        if (n < cap) {
+            base[n * stride] = v;
+            if (tbase) tbase[n * stride] = t;
+            n++;
+        } else {
+            overflow = true;
+        }
+    }
+    RT_HD uint32_t pop_t(float &t) {
+        n--;
+        t = tbase ? tbase[n * stride] : 0.0f;
+        return base[n * stride];
+    }
 };
+RT_HD KdStack make_stack(uint32_t *base, uint32_t stride, uint32_t cap, float *tbase) {
+    KdStack st;
+    st.base = base;
+    st.stride = stride;
+    st.cap = cap;
+    st.n = 0;
+    st.tbase = tbase;
+    st.overflow = false;
+    return st;
+}
 
 struct KdCounters {
     uint32_t nodes, leaves, tris, pops, shapes, mesh_hits;
+    uint32_t wave_steps, wave_tris;  // loop iterations the WAVE executed (one lane counts each): divergence diagnostic
 };
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ uint32_t rt_first_active() {
+    return (uint32_t)(__lane_id() == (unsigned)(__ffsll((long long)__ballot(1)) - 1));
+}
+#else
+inline uint32_t rt_first_active() { return 1u; }
+#endif
 
 // ----------------------------------------------------------------------------- math (C1)
 RT_HD V3 mk(double x, double y, double z) { return V3{x, y, z}; }
@@ -347,6 +407,37 @@ RT_HD void tri_test(const rthip_tri &t, V3 o, V3 d, uint32_t tri, uint32_t ref, 
     }
 }
 
+// Same test for the BVH walk: the mesh-relative triangle index (tie order: the lower index comes
+// first in the reference's walk) is only fetched for accepted hits.
+RT_HD void tri_test_bvh(const rthip_tri &t, V3 o, V3 d, const uint32_t *index, uint32_t pos, TriBest &best) {
+    V3 v0 = mk(t.v0[0], t.v0[1], t.v0[2]);
+    V3 nf = mk(t.face_normal[0], t.face_normal[1], t.face_normal[2]);
+    V3 l = sub(o, v0);
+    double distance = dot(l, nf);
+    if (distance < 0) return;
+    double cosine = dot(d, nf);
+    if (cosine >= 0) return;
+    V3 projection = add(o, scale(d, distance / -cosine));
+    V3 v2 = sub(projection, v0);
+    double d20 = dot(v2, mk(t.e0[0], t.e0[1], t.e0[2]));
+    double d21 = dot(v2, mk(t.e1[0], t.e1[1], t.e1[2]));
+    double v = (t.d11 * d20 - t.d01 * d21) * t.inv_den;
+    double w = (t.d00 * d21 - t.d01 * d20) * t.inv_den;
+    double u = 1.0 - v - w;
+    if (u >= 0 && v >= 0 && w >= 0) {
+        double dd = sqlen(sub(o, projection));
+        if (dd <= best.d) {
+            uint32_t ti = index[pos];
+            if (dd < best.d || (best.hit && ti < best.tri)) {
+                best.d = dd;
+                best.tri = ti;
+                best.ref = ti;
+                best.hit = true;
+            }
+        }
+    }
+}
+
 // Hit point and barycentrics of a triangle already known to be hit (Scene.cpp:446-450, 495-507)
 RT_HD void tri_point(const rthip_tri &t, V3 o, V3 d, V3 &projection, double &u, double &v, double &w) {
     V3 v0 = mk(t.v0[0], t.v0[1], t.v0[2]);
@@ -475,48 +566,58 @@ RT_HD void mesh_closest(const SceneView &sv, const rthip_mesh &m, V3 o, V3 d, Kd
 
 // T4 through the device-oriented BVH: same result as mesh_closest (argmin over the mesh's triangles
 // of the reference's d = |O-P|^2 with the reference's triangle test), different culling structure.
-// Box tests are fp32 and CONSERVATIVE — child boxes are stored rounded outward, every slab interval is
-// widened by `pad`*|1/d| (pad covers the fp32 rounding of the origin and of the plane differences), so
-// a box that could contain a closer-or-equal hit is never skipped; they take no part in the result's
-// arithmetic.  Near child first; the far child is pushed on the LDS stack.
-RT_HD void bvh_slab(const float *lo, const float *hi, float ox, float oy, float oz, float ix, float iy, float iz,
-                    float sx, float sy, float sz, float tmax, float &tn, bool &hit) {
-    float ax = (lo[0] - ox) * ix, bx = (hi[0] - ox) * ix;
-    float ay = (lo[1] - oy) * iy, by = (hi[1] - oy) * iy;
-    float az = (lo[2] - oz) * iz, bz = (hi[2] - oz) * iz;
-    float nx = fminf(ax, bx) - sx, fx = fmaxf(ax, bx) + sx;
-    float ny = fminf(ay, by) - sy, fy = fmaxf(ay, by) + sy;
-    float nz = fminf(az, bz) - sz, fz = fmaxf(az, bz) + sz;
+// Box tests are fp32 and CONSERVATIVE — child boxes are stored rounded outward, and every slab interval
+// is widened by `pad`*|1/d|, so a box that could contain a closer-or-equal hit is never skipped; they
+// take no part in the result's arithmetic.
+// Error budget of one plane parameter a = fma(plane, inv, -(o*inv)) against the exact (plane - O)/D:
+// |a - exact| <= 2^-23 * (1.5|plane| + 2.5|O|) * |1/D|  (roundings of O, D, 1/D, o*inv and the fma),
+// i.e. < 0.32 * 2^-20 * (abs_max + |O|) * |inv|; pad = 2^-20 * (abs_max + max|O|) leaves 3x margin.
+struct BvhRay {
+    float ix, iy, iz;     // clamped reciprocal direction
+    float cx, cy, cz;     // o * inv
+    float sx, sy, sz;     // slab widening per axis
+};
+RT_HD float bvh_inv(double d) {
+    float f = (float)d;
+    float r = 1.0f / f;
+    const float big = 1e30f;  // keeps plane*inv - o*inv and pad*|inv| finite: no inf - inf
+    if (!(fabsf(r) < big)) r = (f < 0.0f || (f == 0.0f && d < 0.0)) ? -big : big;
+    return r;
+}
+RT_HD float rt_fmaf(float a, float b, float c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_fmaf(a, b, c);
+#else
+    return (float)((double)a * (double)b + (double)c);  // test build: double-rounded, within the pad's margin
+#endif
+}
+RT_HD void bvh_slab(const float *lo, const float *hi, const BvhRay &r, float tmax, float &tn, bool &hit) {
+    float ax = rt_fmaf(lo[0], r.ix, -r.cx), bx = rt_fmaf(hi[0], r.ix, -r.cx);
+    float ay = rt_fmaf(lo[1], r.iy, -r.cy), by = rt_fmaf(hi[1], r.iy, -r.cy);
+    float az = rt_fmaf(lo[2], r.iz, -r.cz), bz = rt_fmaf(hi[2], r.iz, -r.cz);
+    float nx = fminf(ax, bx) - r.sx, fx = fmaxf(ax, bx) + r.sx;
+    float ny = fminf(ay, by) - r.sy, fy = fmaxf(ay, by) + r.sy;
+    float nz = fminf(az, bz) - r.sz, fz = fmaxf(az, bz) + r.sz;
     tn = fmaxf(fmaxf(nx, ny), fmaxf(nz, 0.0f));
     float tf = fminf(fminf(fx, fy), fminf(fz, tmax));
     hit = tn <= tf;
 }
-RT_HD float bvh_inv(double d) {
-    float f = (float)d;
-    float r = 1.0f / f;
-    const float big = 1e30f;  // keeps (plane - origin) * inv and pad * |inv| finite: no inf - inf
-    if (!(fabsf(r) < big)) r = (f < 0.0f || (f == 0.0f && d < 0.0)) ? -big : big;
-    return r;
+// upper bound (fp32) of the ray parameter of a hit with squared distance d: sqrt rounded up, two
+// float ulps of margin
+RT_HD float bvh_tmax_of(double d) {
+    float t = (float)sqrt(d);
+    return t + t * 2.4e-7f + 1e-37f;
 }
-RT_HD void bvh_leaf(const rthip_tri *tris, const uint32_t *index, uint32_t word, V3 o, V3 d, TriBest &best, float &tmax,
-                    KdCounters *cnt) {
-    uint32_t first = word & RTHIP_BVH_FIRST_MASK, count = ((word >> RTHIP_BVH_COUNT_SHIFT) & 7u) + 1u;
-    if (cnt) {
-        cnt->leaves++;
-        cnt->tris += count;
-    }
-    for (uint32_t i = 0; i < count; i++) {
-        uint32_t ti = index[first + i];
-        tri_test(tris[first + i], o, d, ti, ti, best);  // ties: lower triangle index (== earlier in the reference walk)
-    }
-    if (best.hit) {
-        // upper bound of the hit parameter: sqrt(d) rounded up, two float ulps of margin
-        float t = (float)sqrt(best.d);
-        tmax = t + t * 2.4e-7f + 1e-37f;
-    }
-}
+// "While-while" walk: every lane first descends through interior nodes until it holds a leaf (or
+// is done), then the wave tests leaf triangles together — a wave never pays for triangle tests on
+// every interior step of its slowest lane.  Near child first; the far child and its entry parameter
+// go to the LDS stack and are culled against the current best when popped.
+// t_stop: in an any-hit query (Raytracer.cpp:305-310 only consumes .Hit) the walk stops looking
+// beyond t_stop once a hit is known; hits up to t_stop are still resolved exactly because the
+// self-intersection test of Scene.cpp:200 applies to the CLOSEST hit (see cast_ray_id).
+template <bool COUNT>
 RT_HD void mesh_closest_bvh(const SceneView &sv, const rthip_mesh &m, V3 o, V3 d, KdStack &st, TriBest &best,
-                            KdCounters *cnt) {
+                            float t_stop, KdCounters *cnt) {
     best.hit = false;
     best.d = DBL_MAX;
     best.tri = 0xffffffffu;
@@ -525,43 +626,70 @@ RT_HD void mesh_closest_bvh(const SceneView &sv, const rthip_mesh &m, V3 o, V3 d
     const rthip_bvhnode *nodes = sv.bvh_nodes + m.bvh_node_base;
     const rthip_tri *tris = sv.bvh_tris + m.bvh_tri_base;
     const uint32_t *index = sv.bvh_tri_index + m.bvh_tri_base;
+    BvhRay r;
     const float ox = (float)o.x, oy = (float)o.y, oz = (float)o.z;
-    const float ix = bvh_inv(d.x), iy = bvh_inv(d.y), iz = bvh_inv(d.z);
-    const float pad = 4.8e-7f * (fmaxf(fmaxf(fabsf(ox), fabsf(oy)), fabsf(oz)) + m.abs_max) + 1e-30f;  // 2^-21 * magnitude
-    const float sx = pad * fabsf(ix), sy = pad * fabsf(iy), sz = pad * fabsf(iz);
+    r.ix = bvh_inv(d.x); r.iy = bvh_inv(d.y); r.iz = bvh_inv(d.z);
+    r.cx = ox * r.ix; r.cy = oy * r.iy; r.cz = oz * r.iz;
+    const float pad = 9.6e-7f * (fmaxf(fmaxf(fabsf(ox), fabsf(oy)), fabsf(oz)) + m.abs_max) + 1e-30f;  // 2^-20 * magnitude
+    r.sx = pad * fabsf(r.ix); r.sy = pad * fabsf(r.iy); r.sz = pad * fabsf(r.iz);
     float tmax = 3.0e38f;
     st.clear();
+    const uint32_t kDone = 0xffffffffu;  // not a valid child word: leaves have count-1 <= 7 in bits 28..30 and first < 2^28
     uint32_t cur = 0;
     for (;;) {
-        const rthip_bvhnode &nd = nodes[cur];
-        if (cnt) cnt->nodes++;
-        float t0, t1;
-        bool h0, h1;
-        bvh_slab(nd.lo0, nd.hi0, ox, oy, oz, ix, iy, iz, sx, sy, sz, tmax, t0, h0);
-        bvh_slab(nd.lo1, nd.hi1, ox, oy, oz, ix, iy, iz, sx, sy, sz, tmax, t1, h1);
-        uint32_t c0 = nd.child0, c1 = nd.child1;
-        // leaves are tested as soon as they are reached (their boxes were just tested)
-        if (h0 && (c0 & RTHIP_BVH_LEAF)) {
-            bvh_leaf(tris, index, c0, o, d, best, tmax, cnt);
-            h0 = false;
-            if (h1 && t1 > tmax) h1 = false;
+        while (cur != kDone && !(cur & RTHIP_BVH_LEAF)) {
+            const rthip_bvhnode &nd = nodes[cur];
+            if (COUNT) {
+                cnt->nodes++;
+                cnt->wave_steps += rt_first_active();
+            }
+            float t0, t1;
+            bool h0, h1;
+            bvh_slab(nd.lo0, nd.hi0, r, tmax, t0, h0);
+            bvh_slab(nd.lo1, nd.hi1, r, tmax, t1, h1);
+            const uint32_t c0 = nd.child0, c1 = nd.child1;
+            if (h0 && h1) {
+                const bool first0 = t0 <= t1;
+                st.push_t(first0 ? c1 : c0, first0 ? t1 : t0);
+                cur = first0 ? c0 : c1;
+            } else if (h0) {
+                cur = c0;
+            } else if (h1) {
+                cur = c1;
+            } else {
+                cur = kDone;
+                while (!st.empty()) {
+                    float t;
+                    uint32_t c = st.pop_t(t);
+                    if (COUNT) cnt->pops++;
+                    if (t <= tmax) { cur = c; break; }
+                }
+            }
         }
-        if (h1 && (c1 & RTHIP_BVH_LEAF)) {
-            bvh_leaf(tris, index, c1, o, d, best, tmax, cnt);
-            h1 = false;
-            if (h0 && t0 > tmax) h0 = false;
+        if (cur == kDone) break;
+        {   // leaf
+            const uint32_t first = cur & RTHIP_BVH_FIRST_MASK, count = ((cur >> RTHIP_BVH_COUNT_SHIFT) & 7u) + 1u;
+            if (COUNT) {
+                cnt->leaves++;
+                cnt->tris += count;
+            }
+            const bool had = best.hit;
+            const double before = best.d;
+            for (uint32_t i = 0; i < count; i++) {
+                if (COUNT) cnt->wave_tris += rt_first_active();
+                tri_test_bvh(tris[first + i], o, d, index, first + i, best);
+            }
+            if (best.hit && (!had || best.d < before)) {
+                tmax = fminf(bvh_tmax_of(best.d), t_stop);
+            }
         }
-        if (h0 && h1) {
-            bool first0 = t0 <= t1;
-            st.push(first0 ? c1 : c0);
-            cur = first0 ? c0 : c1;
-            continue;
+        cur = kDone;
+        while (!st.empty()) {
+            float t;
+            uint32_t c = st.pop_t(t);
+            if (COUNT) cnt->pops++;
+            if (t <= tmax) { cur = c; break; }
         }
-        if (h0) { cur = c0; continue; }
-        if (h1) { cur = c1; continue; }
-        if (st.empty()) break;
-        if (cnt) cnt->pops++;
-        cur = st.pop();
     }
 }
 
@@ -596,27 +724,32 @@ struct Hit {
 };
 
 // Shape::Intersect of one shape in its local frame: hit flag, local hit point, winning triangle
-// FAST = true: meshes go through the BVH only; a degenerate (ray, mesh) pair (kd_degenerate_ray) is not
-// walked but reported through `redo`, and the caller re-runs the whole ray with FAST = false, whose
-// instantiation also contains the reference kd-tree walk.  Keeping that rare path out of the hot
-// kernel keeps its register footprint and code size down.
-template <bool FAST>
-RT_HD bool shape_intersect(const SceneView &sv, const rthip_shape &sh, V3 lo, V3 ld, KdStack &st, V3 &p, int32_t &tri,
-                           bool &redo, KdCounters *cnt) {
+// FAST = true: meshes go through the BVH only; a degenerate (ray, mesh) pair (kd_degenerate_ray) or a
+// BVH stack overflow is not resolved here but reported through `redo`, and the caller re-runs the whole
+// ray with FAST = false, whose instantiation also contains the reference kd-tree walk and a full-depth
+// stack.  Keeping those rare paths out of the hot kernel keeps its register footprint and code size down.
+// t_stop: see mesh_closest_bvh (3e38f for a closest-hit query).
+template <bool FAST, bool COUNT>
+RT_HD bool shape_intersect(const SceneView &sv, int32_t type, int32_t mesh, V3 plane_n, V3 lo, V3 ld, KdStack &st, float t_stop,
+                           V3 &p, int32_t &tri, bool &redo, KdCounters *cnt) {
     tri = -1;
-    if (sh.type == RTHIP_SHAPE_SPHERE) return sphere_intersect(lo, ld, p);
-    if (sh.type == RTHIP_SHAPE_PLANE) return plane_intersect(mk(sh.plane_n[0], sh.plane_n[1], sh.plane_n[2]), lo, ld, p);
-    const rthip_mesh &m = sv.meshes[sh.mesh];
+    if (type == RTHIP_SHAPE_SPHERE) return sphere_intersect(lo, ld, p);
+    if (type == RTHIP_SHAPE_PLANE) return plane_intersect(plane_n, lo, ld, p);
+    const rthip_mesh m = rt_load_mesh(sv.meshes + mesh);  // `mesh` is wave-uniform: scalar loads
     TriBest tb;
     if (FAST) {
         if (kd_degenerate_ray(sv, m, lo, ld)) {
             redo = true;
             return false;
         }
-        mesh_closest_bvh(sv, m, lo, ld, st, tb, cnt);
+        mesh_closest_bvh<COUNT>(sv, m, lo, ld, st, tb, t_stop, cnt);
+        if (st.overflow) {
+            redo = true;
+            return false;
+        }
     } else {
         if (sv.accel == 0 && !kd_degenerate_ray(sv, m, lo, ld))
-            mesh_closest_bvh(sv, m, lo, ld, st, tb, cnt);
+            mesh_closest_bvh<COUNT>(sv, m, lo, ld, st, tb, t_stop, cnt);
         else
             mesh_closest(sv, m, lo, ld, st, tb, cnt);
     }
@@ -627,33 +760,91 @@ RT_HD bool shape_intersect(const SceneView &sv, const rthip_shape &sh, V3 lo, V3
     return true;
 }
 
+// host side of the any-hit bound below (called by rthip_upload_scene)
+// E = fwd*inv - I of a shape's two 3x4 matrices (see rthip_shape.rt_lin / rt_t and anyhit_t_stop)
+inline void roundtrip_bounds(rthip_shape &sh) {
+    double lin = 0.0, tr = 0.0;
+    for (int i = 0; i < 3; i++) {
+        double row = 0.0;
+        for (int j = 0; j < 4; j++) {
+            double e = 0.0, a = 0.0;
+            for (int k = 0; k < 3; k++) {
+                e += sh.fwd[4 * i + k] * sh.inv[4 * k + j];
+                a += fabs(sh.fwd[4 * i + k] * sh.inv[4 * k + j]);
+            }
+            if (j == 3) { e += sh.fwd[4 * i + 3]; a += fabs(sh.fwd[4 * i + 3]); }
+            if (j == i) e -= 1.0;
+            const double bound = fabs(e) + 16.0 * DBL_EPSILON * (a + 1.0);  // |E_ij| plus the rounding of this very sum
+            if (j < 3) row += bound; else tr = fmax(tr, bound);
+        }
+        lin = fmax(lin, row);
+    }
+    sh.rt_lin = 4.0 * lin;
+    sh.rt_t = 4.0 * tr;
+    if (!(sh.rt_lin < 1e300)) sh.rt_lin = 1e300;  // NaN/inf matrices: the device then never stops early
+    if (!(sh.rt_t < 1e300)) sh.rt_t = 1e300;
+}
+
+// Any-hit bound.  A shadow query only needs RaycastResult.Hit, but the reference decides it from the
+// CLOSEST local hit of each shape, accepted iff |O - M*P|^2 >= DBL_EPSILON (Scene.cpp:196-200): a
+// self-hit closer than that masks every farther hit of the same shape.  So once any hit is known the
+// mesh walk may stop looking beyond a local parameter t_stop, provided every hit that could fail the
+// epsilon test lies below t_stop.  The computed world point of a local hit at parameter t is
+// O + E*(O,1) + t*(M*ld) + rounding with E = M*Minv - I, so a computed distance below
+// sqrt(DBL_EPSILON) = 1.5e-8 needs  t*|M*ld| <= 1.5e-8 + |E*(O,1)| + rounding.
+// rt_lin >= ||E_3x3||_inf and rt_t >= |E translation|_inf come from the scene upload (fp64, x4 margin).
+RT_HD float anyhit_t_stop(const double *fwd, double rt_lin, double rt_t, V3 o, V3 ld) {
+    double omax = fmax(fmax(fabs(o.x), fabs(o.y)), fabs(o.z));
+    double tmag = fmax(fmax(fabs(fwd[3]), fabs(fwd[7])), fabs(fwd[11]));
+    double world = 1.5e-8 + 3.0 * rt_lin * omax + rt_t + 1e-9 * (1.0 + omax + tmag);
+    V3 wd = xform(fwd, ld, 0.0);
+    double stretch = length(wd);  // world distance per unit of local parameter
+    double t = world / stretch * 1.001;
+    if (!(t < 1e37)) return 3.0e38f;  // singular transform: no early stop
+    return (float)t * 1.0000002f + 1e-37f;
+}
+
 // Scene::CastRay / CastRayRecursive (Scene.cpp:163-237) over the flat pre-order shape table:
 // per shape world->local ray, Intersect, local->world point, accept iff d^2 >= DBL_EPSILON
 // (Scene.cpp:200), keep the strictly smallest d^2 (earlier node wins ties, Scene.cpp:225).
 // Returns the winning shape (or -1) and its triangle; any_hit stops at the first accepted shape
-// (CastShadowRay only consumes .Hit, Raytracer.cpp:305-310).
-template <bool FAST>
-RT_HD int32_t cast_ray_id(const SceneView &sv, V3 o, V3 d, KdStack &st, bool any_hit, int32_t &best_tri, bool &redo,
-                          KdCounters *cnt) {
+// (CastShadowRay only consumes .Hit, Raytracer.cpp:305-310).  `active` = false makes the call a
+// no-op for this lane: the shape loop runs a wave-uniform number of times so that the shape records
+// are fetched with scalar loads.
+template <bool FAST, bool COUNT>
+RT_HD int32_t cast_ray_id(const SceneView &sv, V3 o, V3 d, KdStack &st, bool any_hit, bool active, int32_t &best_tri,
+                          bool &redo, KdCounters *cnt) {
     int32_t best = -1;
     best_tri = -1;
     double hitDistance = DBL_MAX;
     for (uint32_t s = 0; s < sv.n_shapes; s++) {
-        const rthip_shape &sh = sv.shapes[s];
-        if (cnt) cnt->shapes++;
-        V3 lo = xform(sh.inv, o, 1.0);
-        V3 ld = normalized(xform(sh.inv, d, 0.0));
+        const rt_uniform_shape *sh = rt_uniform_cast(sv.shapes) + s;
+        if (!active) continue;
+        if (COUNT) cnt->shapes++;
+        double inv[12], fwd[12];
+#pragma unroll
+        for (int k = 0; k < 12; k++) {
+            inv[k] = sh->inv[k];
+            fwd[k] = sh->fwd[k];
+        }
+        const int32_t type = sh->type;
+        V3 lo = xform(inv, o, 1.0);
+        V3 ld = normalized(xform(inv, d, 0.0));
         V3 p;
         int32_t tri;
-        if (!shape_intersect<FAST>(sv, sh, lo, ld, st, p, tri, redo, cnt)) continue;
-        V3 worldPoint = xform(sh.fwd, p, 1.0);
+        float t_stop = 3.0e38f;
+        if (any_hit && type == RTHIP_SHAPE_MESH) t_stop = anyhit_t_stop(fwd, sh->rt_lin, sh->rt_t, o, ld);
+        if (!shape_intersect<FAST, COUNT>(sv, type, sh->mesh, mk(sh->plane_n[0], sh->plane_n[1], sh->plane_n[2]), lo, ld, st,
+                                          t_stop, p, tri, redo, cnt))
+            continue;
+        V3 worldPoint = xform(fwd, p, 1.0);
         double distance = sqlen(sub(o, worldPoint));
         if (!(distance >= DBL_EPSILON)) continue;
         if (!(distance < hitDistance)) continue;
         hitDistance = distance;
         best = (int32_t)s;
         best_tri = tri;
-        if (any_hit) break;
+        if (any_hit) active = false;
     }
     return best;
 }
@@ -695,7 +886,10 @@ RT_HD Hit cast_ray(const SceneView &sv, V3 o, V3 d, KdStack &st, bool any_hit, K
     Hit h;
     h.point = h.local = h.normal = mk(0, 0, 0);
     bool redo = false;
-    h.shape = cast_ray_id<false>(sv, o, d, st, any_hit, h.tri, redo, cnt);
+    if (cnt)
+        h.shape = cast_ray_id<false, true>(sv, o, d, st, any_hit, true, h.tri, redo, cnt);
+    else
+        h.shape = cast_ray_id<false, false>(sv, o, d, st, any_hit, true, h.tri, redo, cnt);
     if (h.shape >= 0 && !any_hit) hit_details(sv, o, d, h.shape, h.tri, h, cnt);
     return h;
 }
@@ -713,33 +907,36 @@ struct HitRec {
 // Closest hit, then the shadow queries.  The reference only casts shadow rays when absorptance > 0
 // (Raytracer.cpp:208); casting them unconditionally cannot change the image (their results are unused
 // in that case) and keeps material evaluation out of the traversal kernel.  One cast_ray call site
-// serves both query kinds so the traversal code is instantiated once.
+// serves both query kinds so the traversal code is instantiated once; the query loop runs a
+// wave-uniform number of times (lanes without a hit idle through the shadow queries).
+// n_shadow_lights = 0 gives the single closest-hit query of the DebugRaycaster (Raytracer.cpp:317-351).
 // Returns false (FAST only) when the ray met a degenerate (ray, mesh) pair and must be re-run with FAST = false.
-template <bool FAST>
-RT_HD bool trace_stage(const SceneView &sv, V3 o, V3 d, KdStack &st, HitRec &h, KdCounters *cnt) {
+template <bool FAST, bool COUNT>
+RT_HD bool trace_stage(const SceneView &sv, V3 o, V3 d, uint32_t n_shadow_lights, KdStack &st, HitRec &h, KdCounters *cnt) {
     bool redo = false;
     h.shape = -1;
     h.tri = -1;
     h.shadow_mask = 0;
     h.local = h.normal = mk(0, 0, 0);
     V3 point = mk(0, 0, 0);
-    for (int32_t q = -1; q < (int32_t)sv.n_lights; q++) {
+    for (int32_t q = -1; q < (int32_t)n_shadow_lights; q++) {
         V3 ro = o, rd = d;
+        bool active = !redo;
         if (q >= 0) {
-            if (h.shape < 0) break;
-            const rthip_light &light = sv.lights[q];
-            if (!light.enabled || light.type == RTHIP_LIGHT_AMBIENT) continue;  // Raytracer.cpp:213, 234-237
+            const rt_uniform_light *light = rt_uniform_cast(sv.lights) + q;
+            const int32_t ltype = light->type;
+            if (!light->enabled || ltype == RTHIP_LIGHT_AMBIENT) continue;  // Raytracer.cpp:213, 234-237
+            active = active && h.shape >= 0;
             ro = point;
-            if (light.type == RTHIP_LIGHT_DIRECTIONAL)
-                rd = mk(light.direction[0], light.direction[1], light.direction[2]);
+            if (ltype == RTHIP_LIGHT_DIRECTIONAL)
+                rd = mk(light->direction[0], light->direction[1], light->direction[2]);
             else
-                rd = normalized(sub(mk(light.position[0], light.position[1], light.position[2]), point));
+                rd = normalized(sub(mk(light->position[0], light->position[1], light->position[2]), point));
         }
         int32_t tri;
-        int32_t shape = cast_ray_id<FAST>(sv, ro, rd, st, q >= 0, tri, redo, cnt);
-        if (FAST && redo) return false;
+        int32_t shape = cast_ray_id<FAST, COUNT>(sv, ro, rd, st, q >= 0, active, tri, redo, cnt);
         if (q < 0) {
-            if (shape >= 0) {
+            if (shape >= 0 && !redo) {
                 Hit c;
                 hit_details(sv, o, d, shape, tri, c, cnt);
                 h.shape = shape;
@@ -752,7 +949,7 @@ RT_HD bool trace_stage(const SceneView &sv, V3 o, V3 d, KdStack &st, HitRec &h, 
             h.shadow_mask |= 1u << q;
         }
     }
-    return true;
+    return !(FAST && redo);
 }
 
 struct ShadeOut {
@@ -825,7 +1022,10 @@ struct Bounce {
 // both stages back to back for one ray (probes and the host-compiled test build)
 RT_HD void bounce(const SceneView &sv, V3 ro, V3 rd, bool may_reflect, KdStack &st, Bounce &out, KdCounters *cnt) {
     HitRec h;
-    trace_stage<false>(sv, ro, rd, st, h, cnt);
+    if (cnt)
+        trace_stage<false, true>(sv, ro, rd, sv.n_lights, st, h, cnt);
+    else
+        trace_stage<false, false>(sv, ro, rd, sv.n_lights, st, h, cnt);
     ShadeOut so;
     shade_stage(sv, sv.perlin_tables, h, rd, may_reflect, so);
     out.color = so.color;

@@ -73,8 +73,9 @@ static const uint32_t kBlock = 256;           // 4 waves per workgroup
 #ifndef RT_SHADE_OCC
 #define RT_SHADE_OCC 4
 #endif
+static const uint32_t kFastStackCap = 16;      // entries per lane of the hot kernel's LDS stack (32 KB per workgroup)
 static const uint32_t kMaxGridLevel = 4096;   // queue levels: grid-stride over a bounded grid
-enum { ST_PRIMARY = 0, ST_SHADOW, ST_REFLECT, ST_KD_NODES, ST_KD_TRIS, ST_KD_LEAVES, ST_KD_POPS, ST_SHAPES, ST_MESH_HITS, ST_COUNT };
+enum { ST_PRIMARY = 0, ST_SHADOW, ST_REFLECT, ST_KD_NODES, ST_KD_TRIS, ST_KD_LEAVES, ST_KD_POPS, ST_SHAPES, ST_MESH_HITS, ST_KD_MAXRAY, ST_WAVE_STEPS_MAX, ST_WAVE_TRIS_MAX, ST_WAVE_STEPS, ST_WAVE_TRIS, ST_WAVE_CYCLES_MAX, ST_COUNT };
 
 // Per-frame constants
 struct FrameParams {
@@ -143,30 +144,32 @@ extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[];
 // appended to the redo list and re-traced by the FAST = false instantiation (which also serves
 // accel = 1, the reference kd-tree everywhere).  REDO = true: `n` and the ray indices come from the
 // redo list.
-template <bool FAST, bool REDO>
+template <bool FAST, bool REDO, bool COUNT>
 __global__ __launch_bounds__(kBlock, RT_TRACE_OCC) void k_trace(SceneView sv, FrameParams fp, Work w, uint32_t level,
                                                                  uint32_t stack_cap) {
-    KdStack st;
-    st.base = lds_dyn + threadIdx.x;
-    st.stride = kBlock;
-    st.cap = stack_cap;
-    st.n = 0;
+    // LDS: stack_cap child words per lane, then (FAST only) stack_cap entry parameters per lane
+    KdStack st = make_stack(lds_dyn + threadIdx.x, kBlock, stack_cap,
+                            FAST ? reinterpret_cast<float *>(lds_dyn + (size_t)stack_cap * kBlock) + threadIdx.x : nullptr);
     const uint32_t n = REDO ? w.redo_count[0] : ((level == 0) ? fp.N0 : w.counts[level]);
-    KdCounters kc = {0, 0, 0, 0, 0, 0};
-    KdCounters *kcp = fp.count_kd ? &kc : nullptr;
+    const uint32_t n_shadow = fp.renderer == RTHIP_RENDER_RAYTRACER ? sv.n_lights : 0u;  // DebugRaycaster: closest hit only
+    KdCounters kc = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t max_ray_nodes = 0;
+    const long long t_start = COUNT ? clock64() : 0;
     for (uint32_t base = blockIdx.x * kBlock; base < n; base += gridDim.x * kBlock) {
-        uint32_t j = base + threadIdx.x;
-        if (j >= n) continue;
-        const uint32_t i = REDO ? w.redo[j] : j;
-        V3 o, d;
+        const uint32_t j = base + threadIdx.x;
+        const bool in_range = j < n;
+        const uint32_t i = in_range ? (REDO ? w.redo[j] : j) : 0u;
+        const uint32_t nodes_before = kc.nodes;
+        V3 o = mk(0, 0, 0), d = mk(0, 0, 1);
         uint32_t pix_slot = 0;
+        bool live = in_range;
         if (level == 0) {
             uint32_t s = i / fp.n_pix_slots;  // SSAA sub-sample (0 when aa is off)
             pix_slot = i - s * fp.n_pix_slots;
-            uint32_t x, y;
-            if (!slot_to_pixel(fp, pix_slot, x, y)) {
+            uint32_t x = 0, y = 0;
+            if (live && !slot_to_pixel(fp, pix_slot, x, y)) {
                 w.hit_shape[i] = -2;  // slot outside the image
-                continue;
+                live = false;
             }
             double fx = (double)x, fy = (double)y;
             if (fp.aa) {  // Raytracer.cpp:134-138: dx outer, dy inner, offsets +-0.5
@@ -175,32 +178,23 @@ __global__ __launch_bounds__(kBlock, RT_TRACE_OCC) void k_trace(SceneView sv, Fr
                 fy = (double)((float)(int)y + (float)dy * .5f);
             }
             screen_ray(fp.cam, fp.W, fp.H, fx, fy, o, d);
-            if (!REDO) {
+            if (!REDO && live) {
                 ray_ptr(w, 0, 3)[i] = d.x;  // the shade stage needs the direction (background, reflection)
                 ray_ptr(w, 0, 4)[i] = d.y;
                 ray_ptr(w, 0, 5)[i] = d.z;
             }
-        } else {
+        } else if (live) {
             o = mk(ray_ptr(w, level, 0)[i], ray_ptr(w, level, 1)[i], ray_ptr(w, level, 2)[i]);
             d = mk(ray_ptr(w, level, 3)[i], ray_ptr(w, level, 4)[i], ray_ptr(w, level, 5)[i]);
         }
+        // every lane of the wave walks the (wave-uniform) query and shape loops; dead lanes carry a
+        // ray that is never traced (n_shapes = 0 would need a second code path)
         HitRec h;
+        st.overflow = false;
         bool done = true;
-        if (fp.renderer == RTHIP_RENDER_RAYTRACER) {
-            done = trace_stage<FAST>(sv, o, d, st, h, kcp);
-        } else {  // DebugRaycaster: one closest-hit query, no shadow rays
-            bool redo = false;
-            h.shadow_mask = 0;
-            h.local = h.normal = mk(0, 0, 0);
-            h.shape = cast_ray_id<FAST>(sv, o, d, st, false, h.tri, redo, kcp);
-            done = !(FAST && redo);
-            if (done && h.shape >= 0) {
-                Hit c;
-                hit_details(sv, o, d, h.shape, h.tri, c, kcp);
-                h.local = c.local;
-                h.normal = c.normal;
-            }
-        }
+        if (live) done = trace_stage<FAST, COUNT>(sv, o, d, n_shadow, st, h, COUNT ? &kc : nullptr);
+        if (!live) continue;
+        if (COUNT && kc.nodes - nodes_before > max_ray_nodes) max_ray_nodes = kc.nodes - nodes_before;
         if (FAST && !done) {  // rare: hand the ray to the full instantiation
             w.redo[atomicAdd(&w.redo_count[0], 1u)] = i;
             continue;
@@ -221,7 +215,7 @@ __global__ __launch_bounds__(kBlock, RT_TRACE_OCC) void k_trace(SceneView sv, Fr
             w.id_tri[pix_slot] = h.tri;
         }
     }
-    if (fp.count_kd) {
+    if (COUNT) {
         const uint32_t lane = threadIdx.x & 63u;
         kc.nodes = wave_sum(kc.nodes);
         kc.tris = wave_sum(kc.tris);
@@ -229,7 +223,27 @@ __global__ __launch_bounds__(kBlock, RT_TRACE_OCC) void k_trace(SceneView sv, Fr
         kc.pops = wave_sum(kc.pops);
         kc.shapes = wave_sum(kc.shapes);
         kc.mesh_hits = wave_sum(kc.mesh_hits);
-        if (lane == 0) {
+        kc.wave_steps = wave_sum(kc.wave_steps);
+        kc.wave_tris = wave_sum(kc.wave_tris);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            uint32_t o2 = __shfl_xor(max_ray_nodes, off, 64);
+            max_ray_nodes = o2 > max_ray_nodes ? o2 : max_ray_nodes;
+        }
+        const unsigned long long cycles = (unsigned long long)(clock64() - t_start);
+        if (lane == 0 && fp.count_kd == 2) {  // light mode: only the longest wave (and its step counts), almost no atomics
+            if (cycles > w.stats[ST_WAVE_CYCLES_MAX] && atomicMax(&w.stats[ST_WAVE_CYCLES_MAX], cycles) < cycles) {
+                w.stats[ST_WAVE_STEPS_MAX] = kc.wave_steps;  // racy by design: diagnostics of "a" longest wave
+                w.stats[ST_WAVE_TRIS_MAX] = kc.wave_tris;
+                w.stats[ST_KD_MAXRAY] = max_ray_nodes;
+            }
+        } else if (lane == 0 && (kc.nodes | kc.shapes)) {
+            atomicMax(&w.stats[ST_KD_MAXRAY], (unsigned long long)max_ray_nodes);
+            atomicMax(&w.stats[ST_WAVE_STEPS_MAX], (unsigned long long)kc.wave_steps);
+            atomicMax(&w.stats[ST_WAVE_CYCLES_MAX], cycles);
+            atomicMax(&w.stats[ST_WAVE_TRIS_MAX], (unsigned long long)kc.wave_tris);
+            atomicAdd(&w.stats[ST_WAVE_STEPS], (unsigned long long)kc.wave_steps);
+            atomicAdd(&w.stats[ST_WAVE_TRIS], (unsigned long long)kc.wave_tris);
             atomicAdd(&w.stats[ST_KD_NODES], (unsigned long long)kc.nodes);
             atomicAdd(&w.stats[ST_KD_TRIS], (unsigned long long)kc.tris);
             atomicAdd(&w.stats[ST_KD_LEAVES], (unsigned long long)kc.leaves);
@@ -376,7 +390,7 @@ __global__ __launch_bounds__(kBlock) void k_assemble(FrameParams fp, const uint3
 __global__ __launch_bounds__(kBlock) void k_probe_cast(SceneView sv, uint32_t n, const double *o, const double *d,
                                                        int32_t *hit, double *point, double *local, double *normal,
                                                        int32_t *shape, int32_t *tri, uint32_t stack_cap) {
-    KdStack st{lds_dyn + threadIdx.x, kBlock, stack_cap, 0};
+    KdStack st = make_stack(lds_dyn + threadIdx.x, kBlock, stack_cap, nullptr);
     uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     Hit h = cast_ray(sv, mk(o[3 * i], o[3 * i + 1], o[3 * i + 2]), mk(d[3 * i], d[3 * i + 1], d[3 * i + 2]), st, false, nullptr);
@@ -410,7 +424,7 @@ __global__ __launch_bounds__(kBlock) void k_probe_background(SceneView sv, uint3
 }
 __global__ __launch_bounds__(kBlock) void k_probe_raycast(SceneView sv, uint32_t max_rec, uint32_t n, const double *o,
                                                           const double *d, double *color, uint32_t stack_cap) {
-    KdStack st{lds_dyn + threadIdx.x, kBlock, stack_cap, 0};
+    KdStack st = make_stack(lds_dyn + threadIdx.x, kBlock, stack_cap, nullptr);
     uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     Col c = raycast(sv, mk(o[3 * i], o[3 * i + 1], o[3 * i + 2]), mk(d[3 * i], d[3 * i + 1], d[3 * i + 2]), max_rec, st, nullptr);
@@ -442,7 +456,7 @@ struct rthip_ctx {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     DevBuf bvh_nodes, bvh_tris, bvh_index, kd_planes;
-    uint32_t stack_cap_kd = 1, stack_cap_bvh = 1;
+    uint32_t stack_cap_kd = 1, stack_cap_bvh = 1, stack_cap_full = 1;
     DevBuf shapes, meshes, kd_nodes, kd_bounds, kd_refs, tris, tri_normals, materials, noises, perlin, worley, lights;
     SceneView sv;
     bool has_scene = false;
@@ -486,7 +500,7 @@ int rthip_create(int device, rthip_ctx **out) {
         return fail(RTHIP_E_HIP, "rthip_create: %s", hipGetErrorString(e));
     }
     const char *env = getenv("RTHIP_COUNTERS");
-    c->count_kd = env && atoi(env) != 0;
+    c->count_kd = env ? atoi(env) : 0;
     env = getenv("RTHIP_PROFILE_LAUNCHES");
     c->profile_launches = env && atoi(env) != 0;
     memset(&c->sv, 0, sizeof c->sv);
@@ -647,7 +661,10 @@ int rthip_upload_scene(rthip_ctx *c, const rthip_scene_desc *s) {
     if (set_device(c)) return RTHIP_E_HIP;
     c->has_scene = false;
     HIP_TRY(hipStreamSynchronize(c->stream));
-    if ((rc = upload(c, c->shapes, s->shapes, sizeof(rthip_shape) * s->n_shapes))) return rc;
+    std::vector<rthip_shape> shapes(s->shapes, s->shapes + s->n_shapes);
+    for (rthip_shape &sh : shapes) roundtrip_bounds(sh);
+    if ((rc = upload(c, c->shapes, shapes.data(), sizeof(rthip_shape) * s->n_shapes))) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));  // `shapes` is a local
     if ((rc = upload(c, c->meshes, s->meshes, sizeof(rthip_mesh) * s->n_meshes))) return rc;
     if ((rc = upload(c, c->kd_nodes, s->kd_nodes, sizeof(rthip_kdnode) * s->n_kd_nodes))) return rc;
     if ((rc = upload(c, c->kd_bounds, s->kd_bounds, sizeof(double) * 6 * s->n_kd_nodes))) return rc;
@@ -689,8 +706,8 @@ int rthip_upload_scene(rthip_ctx *c, const rthip_scene_desc *s) {
     v.bg = s->background;
     c->stack_cap_kd = max_depth + 2;
     c->stack_cap_bvh = max_bvh_depth + 2;
-    c->stack_cap_bvh = (max_depth > max_bvh_depth ? max_depth : max_bvh_depth) + 2;  // degenerate rays walk the kd-tree
-    c->stack_cap = c->stack_cap_bvh;
+    c->stack_cap_full = (max_depth > max_bvh_depth ? max_depth : max_bvh_depth) + 2;  // degenerate rays walk the kd-tree
+    c->stack_cap = c->stack_cap_full;
     c->has_scene = true;
     return 0;
 }
@@ -772,15 +789,18 @@ static int render_frame(rthip_ctx *c, const rthip_camera *cam, const rthip_param
     w.N = (uint32_t)N;
 
     c->sv.accel = p->accel;
-    c->stack_cap = p->accel ? c->stack_cap_kd : c->stack_cap_bvh;
+    c->stack_cap = c->stack_cap_full;
     const size_t lds_bytes = (size_t)c->stack_cap * kBlock * sizeof(uint32_t);
     if (lds_bytes > 160 * 1024) return fail(RTHIP_E_UNSUPPORTED, "kd stack of %u entries does not fit LDS", c->stack_cap);
-    if (lds_bytes > 64 * 1024)
-    {
-        HIP_TRY(hipFuncSetAttribute((const void *)k_trace<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        HIP_TRY(hipFuncSetAttribute((const void *)k_trace<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        HIP_TRY(hipFuncSetAttribute((const void *)k_trace<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    if (lds_bytes > 64 * 1024) {
+        HIP_TRY(hipFuncSetAttribute((const void *)k_trace<false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        HIP_TRY(hipFuncSetAttribute((const void *)k_trace<false, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        HIP_TRY(hipFuncSetAttribute((const void *)k_trace<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        HIP_TRY(hipFuncSetAttribute((const void *)k_trace<false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     }
+    // hot kernel: short stack (child word + entry parameter per entry); deeper rays overflow into the redo list
+    const uint32_t cap_fast = c->stack_cap_bvh < kFastStackCap ? c->stack_cap_bvh : kFastStackCap;
+    const size_t lds_fast = (size_t)cap_fast * kBlock * sizeof(uint32_t) * 2;
     const size_t lds_tables = (size_t)c->n_tables * 256;
 
     HIP_TRY(hipMemsetAsync(w.stats, 0, sizeof(unsigned long long) * ST_COUNT, c->stream));
@@ -814,12 +834,22 @@ static int render_frame(rthip_ctx *c, const rthip_camera *cam, const rthip_param
             }
             w.redo_count = w.counts + (RTHIP_MAX_RECURSION + 3) + level;
             if (p->accel == 0) {
-                hipLaunchKernelGGL((k_trace<true, false>), dim3(grid), dim3(kBlock), lds_bytes, c->stream, c->sv, fp, w, level, c->stack_cap);
+                if (c->count_kd)
+                    hipLaunchKernelGGL((k_trace<true, false, true>), dim3(grid), dim3(kBlock), lds_fast, c->stream, c->sv, fp, w, level, cap_fast);
+                else
+                    hipLaunchKernelGGL((k_trace<true, false, false>), dim3(grid), dim3(kBlock), lds_fast, c->stream, c->sv, fp, w, level, cap_fast);
                 if (c->profile_launches) HIP_TRY(hipEventRecord(eb, c->stream));
-                if (c->has_meshes)  // re-trace of the (rare) rays lying exactly in a kd split plane
-                    hipLaunchKernelGGL((k_trace<false, true>), dim3(64), dim3(kBlock), lds_bytes, c->stream, c->sv, fp, w, level, c->stack_cap);
+                if (c->has_meshes) {  // re-trace of the (rare) rays lying exactly in a kd split plane or overflowing the short stack
+                    if (c->count_kd)
+                        hipLaunchKernelGGL((k_trace<false, true, true>), dim3(64), dim3(kBlock), lds_bytes, c->stream, c->sv, fp, w, level, c->stack_cap);
+                    else
+                        hipLaunchKernelGGL((k_trace<false, true, false>), dim3(64), dim3(kBlock), lds_bytes, c->stream, c->sv, fp, w, level, c->stack_cap);
+                }
             } else {
-                hipLaunchKernelGGL((k_trace<false, false>), dim3(grid), dim3(kBlock), lds_bytes, c->stream, c->sv, fp, w, level, c->stack_cap);
+                if (c->count_kd)
+                    hipLaunchKernelGGL((k_trace<false, false, true>), dim3(grid), dim3(kBlock), lds_bytes, c->stream, c->sv, fp, w, level, c->stack_cap);
+                else
+                    hipLaunchKernelGGL((k_trace<false, false, false>), dim3(grid), dim3(kBlock), lds_bytes, c->stream, c->sv, fp, w, level, c->stack_cap);
                 if (c->profile_launches) HIP_TRY(hipEventRecord(eb, c->stream));
             }
             hipLaunchKernelGGL(k_shade, dim3(grid), dim3(kBlock), lds_tables, c->stream, c->sv, fp, w, level, c->n_tables);
@@ -874,12 +904,24 @@ static int finish_stats(rthip_ctx *c, const rthip_params *p) {
     c->last.kd_pops = st[ST_KD_POPS];
     c->last.shape_tests = st[ST_SHAPES];
     c->last.mesh_hits = st[ST_MESH_HITS];
+    c->last.kd_max_nodes_ray = st[ST_KD_MAXRAY];
+    c->last.wave_steps_max = st[ST_WAVE_STEPS_MAX];
+    c->last.wave_tris_max = st[ST_WAVE_TRIS_MAX];
+    c->last.wave_steps = st[ST_WAVE_STEPS];
+    c->last.wave_tris = st[ST_WAVE_TRIS];
+    c->last.wave_cycles_max = st[ST_WAVE_CYCLES_MAX];
+    uint32_t lr[RTHIP_MAX_RECURSION + 1];
+    HIP_TRY(hipMemcpy(lr, c->counts.p, sizeof lr, hipMemcpyDeviceToHost));
+    memset(c->last.level_ms_trace, 0, sizeof c->last.level_ms_trace);
+    for (uint32_t i = 0; i <= RTHIP_MAX_RECURSION; i++) c->last.level_rays[i] = i <= p->max_recursion ? lr[i] : 0;
+    c->last.level_rays[0] = (uint32_t)c->last.rays_primary;
     c->last.ms_total = ms;
     float sum = 0.f;
     for (uint32_t i = 0; i < c->last.launches_trace; i++) {
         float t = 0.f;
         HIP_TRY(hipEventElapsedTime(&t, c->ev_pool[2 * i], c->ev_pool[2 * i + 1]));
         sum += t;
+        if (i <= RTHIP_MAX_RECURSION) c->last.level_ms_trace[i] = t;  // single-chunk frames: launch i = level i
     }
     c->last.ms_trace = sum;
     c->progress.store(1.f);

@@ -37,7 +37,10 @@ class Stats(C.Structure):
                 ("pixels", C.c_uint64), ("ms_total", C.c_float), ("ms_trace", C.c_float),
                 ("launches_trace", C.c_uint32), ("pad", C.c_uint32), ("kd_nodes_visited", C.c_uint64),
                 ("kd_tris_tested", C.c_uint64), ("kd_leaves_visited", C.c_uint64), ("kd_pops", C.c_uint64),
-                ("shape_tests", C.c_uint64), ("mesh_hits", C.c_uint64)]
+                ("shape_tests", C.c_uint64), ("mesh_hits", C.c_uint64), ("kd_max_nodes_ray", C.c_uint64),
+                ("wave_steps_max", C.c_uint64), ("wave_tris_max", C.c_uint64), ("wave_steps", C.c_uint64), ("wave_tris", C.c_uint64),
+                ("wave_cycles_max", C.c_uint64),
+                ("level_rays", C.c_uint32 * 17), ("level_ms_trace", C.c_float * 17)]
 
 
 class RthipError(RuntimeError):

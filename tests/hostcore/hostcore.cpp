@@ -13,9 +13,12 @@ using namespace rtc;
 
 static int g_accel = 0;
 extern "C" void hc_set_accel(int a) { g_accel = a; }
+static std::vector<rthip_shape> g_shapes;  // with the round-trip bounds rthip_upload_scene would fill in
 static SceneView view_of(const rthip_scene_desc *s) {
     SceneView v;
-    v.shapes = s->shapes; v.n_shapes = s->n_shapes; v.meshes = s->meshes;
+    g_shapes.assign(s->shapes, s->shapes + s->n_shapes);
+    for (rthip_shape &sh : g_shapes) roundtrip_bounds(sh);
+    v.shapes = g_shapes.data(); v.n_shapes = s->n_shapes; v.meshes = s->meshes;
     v.kd_nodes = s->kd_nodes; v.kd_bounds = s->kd_bounds; v.kd_refs = s->kd_refs; v.kd_planes = s->kd_planes;
     v.tris = s->tris; v.tri_normals = s->tri_normals; v.bvh_nodes = s->bvh_nodes; v.bvh_tris = s->bvh_tris;
     v.bvh_tri_index = s->bvh_tri_index; v.accel = g_accel; v.materials = s->materials; v.noises = s->noises;
@@ -34,9 +37,10 @@ int hc_render(const rthip_scene_desc *scene, const rthip_camera *cam, const rthi
     std::atomic<uint64_t> total{0}, kn{0}, kl{0}, kt{0};
     auto work = [&]() {
         uint32_t stack_mem[128];
-        KdStack st{stack_mem, 1, 128, 0};
+        float stack_t[128];
+        KdStack st = make_stack(stack_mem, 1, 128, stack_t);
         uint64_t mine = 0;
-        KdCounters kc = {0, 0, 0, 0, 0, 0};
+        KdCounters kc = {0, 0, 0, 0, 0, 0, 0, 0};
         for (;;) {
             uint32_t y = next.fetch_add(1);
             if (y >= p->height) break;
@@ -89,7 +93,8 @@ int hc_cast(const rthip_scene_desc *scene, uint32_t n, const double *o, const do
             double *local, double *normal, int32_t *shape, int32_t *tri) {
     SceneView sv = view_of(scene);
     uint32_t stack_mem[128];
-    KdStack st{stack_mem, 1, 128, 0};
+    float stack_t[128];
+    KdStack st = make_stack(stack_mem, 1, 128, stack_t);
     for (uint32_t i = 0; i < n; i++) {
         Hit h = cast_ray(sv, mk(o[3 * i], o[3 * i + 1], o[3 * i + 2]), mk(d[3 * i], d[3 * i + 1], d[3 * i + 2]), st, false, nullptr);
         hit[i] = h.shape >= 0; shape[i] = h.shape; tri[i] = h.tri;
