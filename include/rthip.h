@@ -91,20 +91,24 @@ typedef struct {
 /* Device-oriented bounding-volume hierarchy over the SAME triangles (no reference counterpart: the
  * reference only has the kd-tree above).  Mesh::Intersect returns the strictly closest triangle hit of
  * the whole mesh (argmin over triangles, Scene.cpp:469-493), so any conservative culling structure
- * yields the same result; this one is binary, 64 bytes per node, child boxes stored in the parent in
- * fp32 rounded OUTWARD.  Child word: bit 31 set = leaf, bits 28..30 = triangle count - 1, bits 0..27 =
- * first triangle in bvh_tris (mesh-relative); else index of the child node (mesh-relative).
- * An absent child has lo = +inf, hi = -inf. */
+ * yields the same result.  This one is 4-wide, 128 bytes per node = one 32-byte slot per child, so the
+ * four lanes that trace one ray together each fetch and test one child (one 128-byte line per ray and
+ * step).  Child boxes are fp32, rounded OUTWARD.  Child word: RTHIP_BVH_ABSENT = no child; bit 31 set =
+ * leaf, bits 28..30 = triangle count - 1 (leaves hold 1..4 triangles, one per lane), bits 0..27 = first
+ * triangle in bvh_tris (mesh-relative); else index of the child node (mesh-relative). */
 typedef struct {
-    float lo0[3], hi0[3];
-    float lo1[3], hi1[3];
-    uint32_t child0, child1;
-    uint32_t pad[2];
+    struct {
+        float lo[3], hi[3];
+        uint32_t child;
+        uint32_t pad;
+    } c[4];
 } rthip_bvhnode;
 #define RTHIP_BVH_LEAF 0x80000000u
+#define RTHIP_BVH_ABSENT 0xffffffffu
 #define RTHIP_BVH_COUNT_SHIFT 28
 #define RTHIP_BVH_FIRST_MASK 0x0fffffffu
-#define RTHIP_BVH_MAX_DEPTH 62
+#define RTHIP_BVH_MAX_LEAF 4
+#define RTHIP_BVH_MAX_DEPTH 48
 
 typedef struct {
     uint32_t node_base, node_count;   /* into kd_nodes / kd_bounds */
@@ -240,9 +244,10 @@ typedef struct {
     uint64_t wave_steps_max, wave_tris_max, wave_steps, wave_tris;
     uint64_t wave_cycles_max;    /* longest-lived trace wave of the frame, shader clock cycles */
     /* per recursion level of the last chunk: rays in the level's queue, and (RTHIP_PROFILE_LAUNCHES=1)
-     * the duration of the level's trace kernel */
+     * the duration of the level's trace kernels and of its shade kernel */
     uint32_t level_rays[RTHIP_MAX_RECURSION + 1];
     float level_ms_trace[RTHIP_MAX_RECURSION + 1];
+    float level_ms_shade[RTHIP_MAX_RECURSION + 1];
 } rthip_stats;
 
 /* ---- lifecycle ---- */

@@ -72,9 +72,9 @@ __device__ __forceinline__ rt_uniform_light *rt_uniform_cast(const rthip_light *
 #else
 typedef const rthip_shape rt_uniform_shape;
 typedef const rthip_light rt_uniform_light;
-inline rt_uniform_shape *rt_uniform_cast(const rthip_shape *p) { return p; }
-inline rt_uniform_light *rt_uniform_cast(const rthip_light *p) { return p; }
-inline rthip_mesh rt_load_mesh(const rthip_mesh *p) { return *p; }
+RT_HD rt_uniform_shape *rt_uniform_cast(const rthip_shape *p) { return p; }
+RT_HD rt_uniform_light *rt_uniform_cast(const rthip_light *p) { return p; }
+RT_HD rthip_mesh rt_load_mesh(const rthip_mesh *p) { return *p; }
 #endif
 
 // Traversal stack: `stride` lets the device interleave the lanes of a workgroup in LDS
@@ -137,7 +137,7 @@ __device__ __forceinline__ uint32_t rt_first_active() {
     return (uint32_t)(__lane_id() == (unsigned)(__ffsll((long long)__ballot(1)) - 1));
 }
 #else
-inline uint32_t rt_first_active() { return 1u; }
+RT_HD uint32_t rt_first_active() { return 1u; }
 #endif
 
 // ----------------------------------------------------------------------------- math (C1)
@@ -602,19 +602,35 @@ RT_HD void bvh_slab(const float *lo, const float *hi, const BvhRay &r, float tma
     float tf = fminf(fminf(fx, fy), fminf(fz, tmax));
     hit = tn <= tf;
 }
+RT_HD BvhRay bvh_ray(V3 o, V3 d, float abs_max) {
+    BvhRay r;
+    const float ox = (float)o.x, oy = (float)o.y, oz = (float)o.z;
+    r.ix = bvh_inv(d.x); r.iy = bvh_inv(d.y); r.iz = bvh_inv(d.z);
+    r.cx = ox * r.ix; r.cy = oy * r.iy; r.cz = oz * r.iz;
+    const float pad = 9.6e-7f * (fmaxf(fmaxf(fabsf(ox), fabsf(oy)), fabsf(oz)) + abs_max) + 1e-30f;  // 2^-20 * magnitude
+    r.sx = pad * fabsf(r.ix); r.sy = pad * fabsf(r.iy); r.sz = pad * fabsf(r.iz);
+    return r;
+}
 // upper bound (fp32) of the ray parameter of a hit with squared distance d: sqrt rounded up, two
 // float ulps of margin
 RT_HD float bvh_tmax_of(double d) {
     float t = (float)sqrt(d);
     return t + t * 2.4e-7f + 1e-37f;
 }
-// "While-while" walk: every lane first descends through interior nodes until it holds a leaf (or
-// is done), then the wave tests leaf triangles together — a wave never pays for triangle tests on
-// every interior step of its slowest lane.  Near child first; the far child and its entry parameter
-// go to the LDS stack and are culled against the current best when popped.
+// One ray per lane over the 4-wide BVH ("while-while": descend through interior nodes until a leaf is
+// held, then test its triangles).  This is the portable form: the CPU test build runs it, and on the
+// device it serves the probes and the redo kernel; the frame kernel walks the same nodes with four
+// lanes per ray (rthip.hip: mesh_closest_quad).  Nearest child first; the other hit children go to
+// the stack far-first with their entry parameters and are culled against the current best when popped.
 // t_stop: in an any-hit query (Raytracer.cpp:305-310 only consumes .Hit) the walk stops looking
 // beyond t_stop once a hit is known; hits up to t_stop are still resolved exactly because the
 // self-intersection test of Scene.cpp:200 applies to the CLOSEST hit (see cast_ray_id).
+RT_HD void bvh_cswap(float &ta, uint32_t &ca, float &tb, uint32_t &cb) {
+    if (tb < ta) {
+        float t = ta; ta = tb; tb = t;
+        uint32_t c = ca; ca = cb; cb = c;
+    }
+}
 template <bool COUNT>
 RT_HD void mesh_closest_bvh(const SceneView &sv, const rthip_mesh &m, V3 o, V3 d, KdStack &st, TriBest &best,
                             float t_stop, KdCounters *cnt) {
@@ -626,38 +642,34 @@ RT_HD void mesh_closest_bvh(const SceneView &sv, const rthip_mesh &m, V3 o, V3 d
     const rthip_bvhnode *nodes = sv.bvh_nodes + m.bvh_node_base;
     const rthip_tri *tris = sv.bvh_tris + m.bvh_tri_base;
     const uint32_t *index = sv.bvh_tri_index + m.bvh_tri_base;
-    BvhRay r;
-    const float ox = (float)o.x, oy = (float)o.y, oz = (float)o.z;
-    r.ix = bvh_inv(d.x); r.iy = bvh_inv(d.y); r.iz = bvh_inv(d.z);
-    r.cx = ox * r.ix; r.cy = oy * r.iy; r.cz = oz * r.iz;
-    const float pad = 9.6e-7f * (fmaxf(fmaxf(fabsf(ox), fabsf(oy)), fabsf(oz)) + m.abs_max) + 1e-30f;  // 2^-20 * magnitude
-    r.sx = pad * fabsf(r.ix); r.sy = pad * fabsf(r.iy); r.sz = pad * fabsf(r.iz);
+    const BvhRay r = bvh_ray(o, d, m.abs_max);
     float tmax = 3.0e38f;
     st.clear();
-    const uint32_t kDone = 0xffffffffu;  // not a valid child word: leaves have count-1 <= 7 in bits 28..30 and first < 2^28
+    const float kMiss = 3.4e38f;
     uint32_t cur = 0;
     for (;;) {
-        while (cur != kDone && !(cur & RTHIP_BVH_LEAF)) {
+        while (!(cur & RTHIP_BVH_LEAF)) {  // RTHIP_BVH_ABSENT (= done) has the leaf bit set
             const rthip_bvhnode &nd = nodes[cur];
-            if (COUNT) {
-                cnt->nodes++;
-                cnt->wave_steps += rt_first_active();
-            }
-            float t0, t1;
-            bool h0, h1;
-            bvh_slab(nd.lo0, nd.hi0, r, tmax, t0, h0);
-            bvh_slab(nd.lo1, nd.hi1, r, tmax, t1, h1);
-            const uint32_t c0 = nd.child0, c1 = nd.child1;
-            if (h0 && h1) {
-                const bool first0 = t0 <= t1;
-                st.push_t(first0 ? c1 : c0, first0 ? t1 : t0);
-                cur = first0 ? c0 : c1;
-            } else if (h0) {
+            if (COUNT) cnt->nodes++;
+            float t0, t1, t2, t3;
+            bool h;
+            uint32_t c0 = nd.c[0].child, c1 = nd.c[1].child, c2 = nd.c[2].child, c3 = nd.c[3].child;
+            bvh_slab(nd.c[0].lo, nd.c[0].hi, r, tmax, t0, h); if (!h || c0 == RTHIP_BVH_ABSENT) t0 = kMiss;
+            bvh_slab(nd.c[1].lo, nd.c[1].hi, r, tmax, t1, h); if (!h || c1 == RTHIP_BVH_ABSENT) t1 = kMiss;
+            bvh_slab(nd.c[2].lo, nd.c[2].hi, r, tmax, t2, h); if (!h || c2 == RTHIP_BVH_ABSENT) t2 = kMiss;
+            bvh_slab(nd.c[3].lo, nd.c[3].hi, r, tmax, t3, h); if (!h || c3 == RTHIP_BVH_ABSENT) t3 = kMiss;
+            bvh_cswap(t0, c0, t1, c1);  // sorting network, ascending entry parameter
+            bvh_cswap(t2, c2, t3, c3);
+            bvh_cswap(t0, c0, t2, c2);
+            bvh_cswap(t1, c1, t3, c3);
+            bvh_cswap(t1, c1, t2, c2);
+            if (t3 < kMiss) st.push_t(c3, t3);
+            if (t2 < kMiss) st.push_t(c2, t2);
+            if (t1 < kMiss) st.push_t(c1, t1);
+            if (t0 < kMiss) {
                 cur = c0;
-            } else if (h1) {
-                cur = c1;
             } else {
-                cur = kDone;
+                cur = RTHIP_BVH_ABSENT;
                 while (!st.empty()) {
                     float t;
                     uint32_t c = st.pop_t(t);
@@ -666,7 +678,7 @@ RT_HD void mesh_closest_bvh(const SceneView &sv, const rthip_mesh &m, V3 o, V3 d
                 }
             }
         }
-        if (cur == kDone) break;
+        if (cur == RTHIP_BVH_ABSENT) break;
         {   // leaf
             const uint32_t first = cur & RTHIP_BVH_FIRST_MASK, count = ((cur >> RTHIP_BVH_COUNT_SHIFT) & 7u) + 1u;
             if (COUNT) {
@@ -675,15 +687,10 @@ RT_HD void mesh_closest_bvh(const SceneView &sv, const rthip_mesh &m, V3 o, V3 d
             }
             const bool had = best.hit;
             const double before = best.d;
-            for (uint32_t i = 0; i < count; i++) {
-                if (COUNT) cnt->wave_tris += rt_first_active();
-                tri_test_bvh(tris[first + i], o, d, index, first + i, best);
-            }
-            if (best.hit && (!had || best.d < before)) {
-                tmax = fminf(bvh_tmax_of(best.d), t_stop);
-            }
+            for (uint32_t i = 0; i < count; i++) tri_test_bvh(tris[first + i], o, d, index, first + i, best);
+            if (best.hit && (!had || best.d < before)) tmax = fminf(bvh_tmax_of(best.d), t_stop);
         }
-        cur = kDone;
+        cur = RTHIP_BVH_ABSENT;
         while (!st.empty()) {
             float t;
             uint32_t c = st.pop_t(t);

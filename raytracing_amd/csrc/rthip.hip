@@ -70,12 +70,15 @@ static const uint32_t kBlock = 256;           // 4 waves per workgroup
 #ifndef RT_TRACE_OCC
 #define RT_TRACE_OCC 4
 #endif
+#ifndef RT_QUAD_OCC
+#define RT_QUAD_OCC 4
+#endif
 #ifndef RT_SHADE_OCC
 #define RT_SHADE_OCC 4
 #endif
-static const uint32_t kFastStackCap = 16;      // entries per lane of the hot kernel's LDS stack (32 KB per workgroup)
+static const uint32_t kMaxGridQuad = 16384;    // same for the quad kernel (64 rays per workgroup)
 static const uint32_t kMaxGridLevel = 4096;   // queue levels: grid-stride over a bounded grid
-enum { ST_PRIMARY = 0, ST_SHADOW, ST_REFLECT, ST_KD_NODES, ST_KD_TRIS, ST_KD_LEAVES, ST_KD_POPS, ST_SHAPES, ST_MESH_HITS, ST_KD_MAXRAY, ST_WAVE_STEPS_MAX, ST_WAVE_TRIS_MAX, ST_WAVE_STEPS, ST_WAVE_TRIS, ST_WAVE_CYCLES_MAX, ST_COUNT };
+enum { ST_KD_NODES = 0, ST_KD_TRIS, ST_KD_LEAVES, ST_KD_POPS, ST_SHAPES, ST_MESH_HITS, ST_KD_MAXRAY, ST_WAVE_STEPS_MAX, ST_WAVE_TRIS_MAX, ST_WAVE_STEPS, ST_WAVE_TRIS, ST_WAVE_CYCLES_MAX, ST_COUNT };
 
 // Per-frame constants
 struct FrameParams {
@@ -89,32 +92,69 @@ struct FrameParams {
     uint32_t count_kd;     // collect kd counters
     int32_t layout;        // 0 frame, 1 tile-compact
 };
-// Per-frame device workspace (struct-of-arrays; N = capacity of one level)
+// Per-frame device workspace.  Every per-ray record is ONE aligned array-of-structs entry (a 64-byte
+// ray, a 64-byte hit, a 32-byte colour): a lane reads or writes whole cache lines with dwordx4
+// accesses.  (Seven separate 8-byte arrays written at compacted offsets cost 0.2 ms per 1 M spawned
+// rays on MI355X; the same data as one 64-byte store per lane is free.)
+struct __attribute__((aligned(64))) RayRec {
+    double ox, oy, oz, dx, dy, dz;
+    uint32_t parent;  // index of the spawning ray in the previous level
+    uint32_t pad;
+};
+struct __attribute__((aligned(64))) HitSlot {
+    double lx, ly, lz, nx, ny, nz;  // RaycastResult.LocalPoint / .Normal
+    int32_t shape;                  // shape ordinal, -1 miss, -2 no ray (slot outside the image)
+    uint32_t mask;                  // shadow mask
+};
+struct __attribute__((aligned(32))) ColRec {
+    double r, g, b, refl;  // direct colour (later: folded colour) and the reflectance applied to the child
+};
 struct Work {
-    double *rec;            // [levels][4][N]: colour r,g,b + reflectance of every ray of a level
+    ColRec *rec;            // [levels][N]
     uint32_t *parent;       // [levels][N]  : index of the spawning ray in level-1
-    double *rays;           // [2][6][N]    : ping-pong ray queues (o.xyz, d.xyz)
+    RayRec *rays;           // [2][N]       : ping-pong ray queues
     uint32_t *counts;       // [levels+1]   : rays per level
     unsigned long long *stats;  // [ST_COUNT]
     int32_t *id_shape, *id_tri; // [n_pix_slots] primary-hit ids (optional)
-    int32_t *hit_shape;         // [N] per ray of the current level: shape ordinal, -1 miss, -2 no ray
-    uint32_t *hit_mask;         // [N] shadow mask
-    double *hit;                // [6][N] local point, normal
+    HitSlot *hit;               // [N] per ray of the current level
     uint32_t *redo;             // [N] rays of the current level that must be re-traced by the full kernel
     uint32_t *redo_count;       // [levels] one counter per level (zeroed with `counts`)
+    uint32_t *hard;             // [N] rays of the current level that need a mesh walk (traced by the quad kernel)
+    uint32_t *hard_count;       // [levels]
+    uint2 *block_stats;         // [levels][bs_stride] per workgroup of k_shade: (shadow queries, reflected rays) of the frame
+    uint32_t bs_stride;
     uint32_t N;
 };
 
-__device__ __forceinline__ double *rec_ptr(const Work &w, uint32_t level, uint32_t comp) {
-    return w.rec + ((size_t)level * 4 + comp) * w.N;
+__device__ __forceinline__ ColRec &rec_at(const Work &w, uint32_t level, uint32_t i) { return w.rec[(size_t)level * w.N + i]; }
+__device__ __forceinline__ RayRec &ray_at(const Work &w, uint32_t level, uint32_t i) { return w.rays[(size_t)(level & 1) * w.N + i]; }
+__device__ __forceinline__ void store_ray(const Work &w, uint32_t level, uint32_t i, V3 o, V3 d, uint32_t parent) {
+    RayRec r;
+    r.ox = o.x; r.oy = o.y; r.oz = o.z;
+    r.dx = d.x; r.dy = d.y; r.dz = d.z;
+    r.parent = parent;
+    r.pad = 0;
+    ray_at(w, level, i) = r;
 }
-__device__ __forceinline__ double *hit_ptr(const Work &w, uint32_t comp) { return w.hit + (size_t)comp * w.N; }
-__device__ __forceinline__ double *ray_ptr(const Work &w, uint32_t level, uint32_t comp) {
-    return w.rays + ((size_t)(level & 1) * 6 + comp) * w.N;
+__device__ __forceinline__ void store_hit(const Work &w, uint32_t i, const HitRec &h) {
+    HitSlot s;
+    s.lx = h.local.x; s.ly = h.local.y; s.lz = h.local.z;
+    s.nx = h.normal.x; s.ny = h.normal.y; s.nz = h.normal.z;
+    s.shape = h.shape;
+    s.mask = h.shadow_mask;
+    w.hit[i] = s;
+}
+__device__ __forceinline__ void store_no_ray(const Work &w, uint32_t i) {
+    HitSlot s;
+    s.lx = s.ly = s.lz = s.nx = s.ny = s.nz = 0.0;
+    s.shape = -2;
+    s.mask = 0;
+    w.hit[i] = s;
 }
 
 // slot (within chunk) -> pixel.  Tiles are tile_w x tile_h; inside a tile the pixels are ordered
-// as 8x8 sub-blocks so that one 64-lane wave covers a compact 8x8 patch of the screen.
+// as 8x8 sub-blocks, and inside a sub-block as four 4x4 patches: 16 consecutive slots (the rays of one
+// wave of the quad trace kernel) cover a compact 4x4 patch, 64 (one shade wave) an 8x8 one.
 __device__ __forceinline__ bool slot_to_pixel(const FrameParams &fp, uint32_t pix_slot, uint32_t &x, uint32_t &y) {
     uint32_t per_tile = fp.tile_w * fp.tile_h;
     uint32_t q = fp.q0 + pix_slot / per_tile;
@@ -124,8 +164,8 @@ __device__ __forceinline__ bool slot_to_pixel(const FrameParams &fp, uint32_t pi
     uint32_t tx = t % fp.tiles_x, ty = t / fp.tiles_x;
     uint32_t sb = r >> 6, l = r & 63u;
     uint32_t sbx = fp.tile_w >> 3;
-    x = tx * fp.tile_w + (sb % sbx) * 8 + (l & 7u);
-    y = ty * fp.tile_h + (sb / sbx) * 8 + (l >> 3);
+    x = tx * fp.tile_w + (sb % sbx) * 8 + ((l & 3u) | ((l >> 2) & 4u));
+    y = ty * fp.tile_h + (sb / sbx) * 8 + (((l >> 2) & 3u) | ((l >> 3) & 4u));
     return x < fp.W && y < fp.H;
 }
 
@@ -138,84 +178,8 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 // ============================================================================ kernels
 extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[];
 
-// Stage 1 of a level: every scene query of the level (SURVEY.md §8a S1, P1, P2, T2, T4, R6).
-// Level 0 generates its rays (R1).  Output: one HitRec per ray (SoA) + the ray direction.
-// FAST = true is the hot instantiation: BVH only; rays that meet a degenerate (ray, mesh) pair are
-// appended to the redo list and re-traced by the FAST = false instantiation (which also serves
-// accel = 1, the reference kd-tree everywhere).  REDO = true: `n` and the ray indices come from the
-// redo list.
-template <bool FAST, bool REDO, bool COUNT>
-__global__ __launch_bounds__(kBlock, RT_TRACE_OCC) void k_trace(SceneView sv, FrameParams fp, Work w, uint32_t level,
-                                                                 uint32_t stack_cap) {
-    // LDS: stack_cap child words per lane, then (FAST only) stack_cap entry parameters per lane
-    KdStack st = make_stack(lds_dyn + threadIdx.x, kBlock, stack_cap,
-                            FAST ? reinterpret_cast<float *>(lds_dyn + (size_t)stack_cap * kBlock) + threadIdx.x : nullptr);
-    const uint32_t n = REDO ? w.redo_count[0] : ((level == 0) ? fp.N0 : w.counts[level]);
-    const uint32_t n_shadow = fp.renderer == RTHIP_RENDER_RAYTRACER ? sv.n_lights : 0u;  // DebugRaycaster: closest hit only
-    KdCounters kc = {0, 0, 0, 0, 0, 0, 0, 0};
-    uint32_t max_ray_nodes = 0;
-    const long long t_start = COUNT ? clock64() : 0;
-    for (uint32_t base = blockIdx.x * kBlock; base < n; base += gridDim.x * kBlock) {
-        const uint32_t j = base + threadIdx.x;
-        const bool in_range = j < n;
-        const uint32_t i = in_range ? (REDO ? w.redo[j] : j) : 0u;
-        const uint32_t nodes_before = kc.nodes;
-        V3 o = mk(0, 0, 0), d = mk(0, 0, 1);
-        uint32_t pix_slot = 0;
-        bool live = in_range;
-        if (level == 0) {
-            uint32_t s = i / fp.n_pix_slots;  // SSAA sub-sample (0 when aa is off)
-            pix_slot = i - s * fp.n_pix_slots;
-            uint32_t x = 0, y = 0;
-            if (live && !slot_to_pixel(fp, pix_slot, x, y)) {
-                w.hit_shape[i] = -2;  // slot outside the image
-                live = false;
-            }
-            double fx = (double)x, fy = (double)y;
-            if (fp.aa) {  // Raytracer.cpp:134-138: dx outer, dy inner, offsets +-0.5
-                int dx = (int)(s / 3) - 1, dy = (int)(s % 3) - 1;
-                fx = (double)((float)x + (float)dx * .5f);
-                fy = (double)((float)(int)y + (float)dy * .5f);
-            }
-            screen_ray(fp.cam, fp.W, fp.H, fx, fy, o, d);
-            if (!REDO && live) {
-                ray_ptr(w, 0, 3)[i] = d.x;  // the shade stage needs the direction (background, reflection)
-                ray_ptr(w, 0, 4)[i] = d.y;
-                ray_ptr(w, 0, 5)[i] = d.z;
-            }
-        } else if (live) {
-            o = mk(ray_ptr(w, level, 0)[i], ray_ptr(w, level, 1)[i], ray_ptr(w, level, 2)[i]);
-            d = mk(ray_ptr(w, level, 3)[i], ray_ptr(w, level, 4)[i], ray_ptr(w, level, 5)[i]);
-        }
-        // every lane of the wave walks the (wave-uniform) query and shape loops; dead lanes carry a
-        // ray that is never traced (n_shapes = 0 would need a second code path)
-        HitRec h;
-        st.overflow = false;
-        bool done = true;
-        if (live) done = trace_stage<FAST, COUNT>(sv, o, d, n_shadow, st, h, COUNT ? &kc : nullptr);
-        if (!live) continue;
-        if (COUNT && kc.nodes - nodes_before > max_ray_nodes) max_ray_nodes = kc.nodes - nodes_before;
-        if (FAST && !done) {  // rare: hand the ray to the full instantiation
-            w.redo[atomicAdd(&w.redo_count[0], 1u)] = i;
-            continue;
-        }
-        w.hit_shape[i] = h.shape;
-        if (h.shape >= 0) {
-            w.hit_mask[i] = h.shadow_mask;
-            hit_ptr(w, 0)[i] = h.local.x;
-            hit_ptr(w, 1)[i] = h.local.y;
-            hit_ptr(w, 2)[i] = h.local.z;
-            hit_ptr(w, 3)[i] = h.normal.x;
-            hit_ptr(w, 4)[i] = h.normal.y;
-            hit_ptr(w, 5)[i] = h.normal.z;
-        }
-        // primary-hit ids come from the un-offset pixel-centre ray (sub-sample 4 of the 3x3 SSAA grid)
-        if (level == 0 && w.id_shape && i / fp.n_pix_slots == (fp.aa ? 4u : 0u)) {
-            w.id_shape[pix_slot] = h.shape;
-            w.id_tri[pix_slot] = h.tri;
-        }
-    }
-    if (COUNT) {
+// COUNT instantiations: wave-reduced traversal counters -> w.stats (fp.count_kd == 2: only the longest wave)
+__device__ __forceinline__ void trace_counters_flush(const FrameParams &fp, const Work &w, KdCounters kc, uint32_t max_ray_nodes, long long t_start) {
         const uint32_t lane = threadIdx.x & 63u;
         kc.nodes = wave_sum(kc.nodes);
         kc.tris = wave_sum(kc.tris);
@@ -251,7 +215,579 @@ __global__ __launch_bounds__(kBlock, RT_TRACE_OCC) void k_trace(SceneView sv, Fr
             atomicAdd(&w.stats[ST_SHAPES], (unsigned long long)kc.shapes);
             atomicAdd(&w.stats[ST_MESH_HITS], (unsigned long long)kc.mesh_hits);
         }
+}
+
+// Stage 1 of a level: every scene query of the level (SURVEY.md §8a S1, P1, P2, T2, T4, R6).
+// Level 0 generates its rays (R1).  Output: one HitRec per ray (SoA) + the ray direction.
+// FAST = true is the hot instantiation: BVH only; rays that meet a degenerate (ray, mesh) pair are
+// appended to the redo list and re-traced by the FAST = false instantiation (which also serves
+// accel = 1, the reference kd-tree everywhere).  REDO = true: `n` and the ray indices come from the
+// redo list.
+template <bool FAST, bool REDO, bool COUNT>
+__global__ __launch_bounds__(kBlock, RT_TRACE_OCC) void k_trace(SceneView sv, FrameParams fp, Work w, uint32_t level,
+                                                                 uint32_t stack_cap) {
+    // LDS: stack_cap child words per lane, then (FAST only) stack_cap entry parameters per lane
+    KdStack st = make_stack(lds_dyn + threadIdx.x, kBlock, stack_cap,
+                            FAST ? reinterpret_cast<float *>(lds_dyn + (size_t)stack_cap * kBlock) + threadIdx.x : nullptr);
+    const uint32_t n = REDO ? w.redo_count[0] : ((level == 0) ? fp.N0 : w.counts[level]);
+    const uint32_t n_shadow = fp.renderer == RTHIP_RENDER_RAYTRACER ? sv.n_lights : 0u;  // DebugRaycaster: closest hit only
+    KdCounters kc = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t max_ray_nodes = 0;
+    const long long t_start = COUNT ? clock64() : 0;
+    for (uint32_t base = blockIdx.x * kBlock; base < n; base += gridDim.x * kBlock) {
+        const uint32_t j = base + threadIdx.x;
+        const bool in_range = j < n;
+        const uint32_t i = in_range ? (REDO ? w.redo[j] : j) : 0u;
+        const uint32_t nodes_before = kc.nodes;
+        V3 o = mk(0, 0, 0), d = mk(0, 0, 1);
+        uint32_t pix_slot = 0;
+        bool live = in_range;
+        if (level == 0) {
+            uint32_t s = i / fp.n_pix_slots;  // SSAA sub-sample (0 when aa is off)
+            pix_slot = i - s * fp.n_pix_slots;
+            uint32_t x = 0, y = 0;
+            if (live && !slot_to_pixel(fp, pix_slot, x, y)) {
+                store_no_ray(w, i);  // slot outside the image
+                live = false;
+            }
+            double fx = (double)x, fy = (double)y;
+            if (fp.aa) {  // Raytracer.cpp:134-138: dx outer, dy inner, offsets +-0.5
+                int dx = (int)(s / 3) - 1, dy = (int)(s % 3) - 1;
+                fx = (double)((float)x + (float)dx * .5f);
+                fy = (double)((float)(int)y + (float)dy * .5f);
+            }
+            screen_ray(fp.cam, fp.W, fp.H, fx, fy, o, d);
+            if (!REDO && live) {
+                store_ray(w, 0, i, o, d, 0u);  // the shade stage needs the direction (background, reflection)
+            }
+        } else if (live) {
+            const RayRec r = ray_at(w, level, i);
+            o = mk(r.ox, r.oy, r.oz);
+            d = mk(r.dx, r.dy, r.dz);
+        }
+        // every lane of the wave walks the (wave-uniform) query and shape loops; dead lanes carry a
+        // ray that is never traced (n_shapes = 0 would need a second code path)
+        HitRec h;
+        st.overflow = false;
+        bool done = true;
+        if (live) done = trace_stage<FAST, COUNT>(sv, o, d, n_shadow, st, h, COUNT ? &kc : nullptr);
+        if (!live) continue;
+        if (COUNT && kc.nodes - nodes_before > max_ray_nodes) max_ray_nodes = kc.nodes - nodes_before;
+        if (FAST && !done) {  // rare: hand the ray to the full instantiation
+            w.redo[atomicAdd(&w.redo_count[0], 1u)] = i;
+            continue;
+        }
+        store_hit(w, i, h);
+        // primary-hit ids come from the un-offset pixel-centre ray (sub-sample 4 of the 3x3 SSAA grid)
+        if (level == 0 && w.id_shape && i / fp.n_pix_slots == (fp.aa ? 4u : 0u)) {
+            w.id_shape[pix_slot] = h.shape;
+            w.id_tri[pix_slot] = h.tri;
+        }
     }
+    if (COUNT) trace_counters_flush(fp, w, kc, max_ray_nodes, t_start);
+}
+
+// ============================================================================ four lanes per ray
+// The frame's trace kernel.  A ray is owned by a QUAD of four adjacent lanes (16 rays per wave):
+//  * analytic shapes (spheres, planes) are spread over the four lanes, one shape per lane and pass;
+//  * a mesh is walked by the four lanes together over the 4-wide BVH: each lane fetches the 32-byte
+//    slot of ONE child (the quad reads one 128-byte line per step), tests its box, and the quad ranks
+//    the hit children with DPP quad permutes; the nearest is entered, the others go to the quad's LDS
+//    stack far-first with their entry parameters;
+//  * a leaf holds up to four triangles: each lane runs the exact fp64 test of one, the quad reduces.
+// Compared with one ray per lane this cuts the dependent steps of a ray (4 boxes / 4 triangles per
+// step), divides the lanes whose slowest member a wave waits for by four, and turns 64 scattered
+// 64-byte gathers per wave-load into 16 full lines.  Every branch that encloses a cross-lane
+// operation is quad-uniform by construction (ray state is replicated bit-identically in the 4 lanes).
+namespace quad {
+constexpr int kXor1 = 0xB1, kXor2 = 0x4E, kRot1 = 0x39, kRot3 = 0x93;  // quad_perm [1,0,3,2] [2,3,0,1] [1,2,3,0] [3,0,1,2]
+static const uint32_t kCap = 24, kStride = 25;  // stack entries per quad; odd stride spreads the LDS banks
+static const uint32_t kRaysPerBlock = kBlock / 4;
+
+template <int CTRL> __device__ __forceinline__ uint32_t dpp(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true);
+}
+template <int CTRL> __device__ __forceinline__ double dpp(double v) {
+    unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    uint32_t lo = dpp<CTRL>((uint32_t)b), hi = dpp<CTRL>((uint32_t)(b >> 32));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+struct Stack {
+    uint32_t *w;
+    float *t;
+};
+
+// lexicographic min of (d, id) over the quad; id = 0xffffffff means "nothing"
+__device__ __forceinline__ void reduce_min(double &d, uint32_t &id) {
+    {
+        double od = dpp<kXor1>(d);
+        uint32_t oi = dpp<kXor1>(id);
+        if (od < d || (od == d && oi < id)) { d = od; id = oi; }
+    }
+    {
+        double od = dpp<kXor2>(d);
+        uint32_t oi = dpp<kXor2>(id);
+        if (od < d || (od == d && oi < id)) { d = od; id = oi; }
+    }
+}
+
+// Scene.cpp:421-467 + :495-507 for one triangle: accepted? and the reference's d = |O - P|^2
+__device__ __forceinline__ bool tri_eval(const rthip_tri &t, V3 o, V3 d, double &dd) {
+    V3 v0 = mk(t.v0[0], t.v0[1], t.v0[2]);
+    V3 nf = mk(t.face_normal[0], t.face_normal[1], t.face_normal[2]);
+    double distance = dot(sub(o, v0), nf);
+    if (distance < 0) return false;
+    double cosine = dot(d, nf);
+    if (cosine >= 0) return false;
+    V3 projection = add(o, scale(d, distance / -cosine));
+    V3 v2 = sub(projection, v0);
+    double d20 = dot(v2, mk(t.e0[0], t.e0[1], t.e0[2]));
+    double d21 = dot(v2, mk(t.e1[0], t.e1[1], t.e1[2]));
+    double v = (t.d11 * d20 - t.d01 * d21) * t.inv_den;
+    double w = (t.d00 * d21 - t.d01 * d20) * t.inv_den;
+    double u = 1.0 - v - w;
+    if (!(u >= 0 && v >= 0 && w >= 0)) return false;
+    dd = sqlen(sub(o, projection));
+    return true;
+}
+
+template <bool COUNT>
+__device__ __forceinline__ void mesh_closest(const SceneView &sv, const rthip_mesh &m, V3 o, V3 d, Stack qs, uint32_t q,
+                                             float t_stop, TriBest &best, bool &overflow, KdCounters &cnt) {
+    best.hit = false;
+    best.d = DBL_MAX;
+    best.tri = 0xffffffffu;
+    best.ref = 0xffffffffu;
+    if (m.bvh_node_count == 0) return;
+    const char *nodes = reinterpret_cast<const char *>(sv.bvh_nodes + m.bvh_node_base) + (q << 5);
+    const rthip_tri *tris = sv.bvh_tris + m.bvh_tri_base;
+    const uint32_t *index = sv.bvh_tri_index + m.bvh_tri_base;
+    const BvhRay r = bvh_ray(o, d, m.abs_max);
+    float tmax = 3.0e38f;
+    uint32_t n = 0;
+    uint32_t cur = 0;
+    auto pop = [&]() {
+        uint32_t c = RTHIP_BVH_ABSENT;
+        while (n) {
+            n--;
+            const float t = qs.t[n];
+            const uint32_t cw = qs.w[n];
+            if (COUNT) cnt.pops += (q == 0);
+            if (t <= tmax) { c = cw; break; }
+        }
+        return c;
+    };
+    for (;;) {
+        while (!(cur & RTHIP_BVH_LEAF)) {  // RTHIP_BVH_ABSENT (= done) has the leaf bit set
+            const uint4 *p = reinterpret_cast<const uint4 *>(nodes + ((size_t)cur << 7));
+            const uint4 A = p[0], B = p[1];  // lo.xyz hi.x | hi.yz child pad
+            if (COUNT) {
+                cnt.nodes += (q == 0);
+                cnt.wave_steps += rt_first_active();
+            }
+            const float lo[3] = {__uint_as_float(A.x), __uint_as_float(A.y), __uint_as_float(A.z)};
+            const float hi[3] = {__uint_as_float(A.w), __uint_as_float(B.x), __uint_as_float(B.y)};
+            const uint32_t child = B.z;
+            float tn;
+            bool h;
+            bvh_slab(lo, hi, r, tmax, tn, h);
+            h = h && child != RTHIP_BVH_ABSENT;
+            const uint32_t kNone = 0xfffffffcu;
+            const uint32_t key = h ? ((__float_as_uint(tn) & ~3u) | q) : (kNone | q);  // tn >= 0: bit order == value order
+            const uint32_t k1 = dpp<kRot1>(key), k2 = dpp<kXor2>(key), k3 = dpp<kRot3>(key);
+            const uint32_t rank = (uint32_t)(k1 < key) + (uint32_t)(k2 < key) + (uint32_t)(k3 < key);
+            const uint32_t nhit = (uint32_t)h + (uint32_t)(k1 < kNone) + (uint32_t)(k2 < kNone) + (uint32_t)(k3 < kNone);
+            uint32_t sel = (h && rank == 0) ? child : 0u;  // node indices are >= 1 below the root, leaf words have bit 31
+            sel |= dpp<kXor1>(sel);
+            sel |= dpp<kXor2>(sel);
+            if (nhit > 1) {
+                if (n + nhit - 1 > kCap) {  // rare: the redo kernel walks this ray with a full-depth stack
+                    overflow = true;
+                    return;
+                }
+                if (h && rank) {
+                    const uint32_t slot = n + nhit - 1 - rank;  // nearest of the rest on top
+                    qs.w[slot] = child;
+                    qs.t[slot] = tn;
+                }
+                n += nhit - 1;
+            }
+            cur = nhit ? sel : pop();
+        }
+        if (cur == RTHIP_BVH_ABSENT) break;
+        {   // leaf: one triangle per lane
+            const uint32_t first = cur & RTHIP_BVH_FIRST_MASK, count = ((cur >> RTHIP_BVH_COUNT_SHIFT) & 7u) + 1u;
+            if (COUNT) {
+                cnt.leaves += (q == 0);
+                cnt.tris += (q == 0) ? count : 0u;
+                cnt.wave_tris += rt_first_active();
+            }
+            double dd = DBL_MAX;
+            uint32_t ti = 0xffffffffu;
+            if (q < count) {
+                double e;
+                if (tri_eval(tris[first + q], o, d, e)) {
+                    dd = e;
+                    ti = index[first + q];
+                }
+            }
+            reduce_min(dd, ti);
+            // strict '<' of Scene.cpp:479; exact ties keep the triangle that comes first in the reference's walk
+            if (ti != 0xffffffffu && (dd < best.d || (dd == best.d && ti < best.tri))) {
+                best.d = dd;
+                best.tri = ti;
+                best.ref = ti;
+                best.hit = true;
+                tmax = fminf(bvh_tmax_of(dd), t_stop);
+            }
+        }
+        cur = pop();
+    }
+}
+
+// Scene::CastRay (Scene.cpp:163-237) for the quad's ray; same contract as rtc::cast_ray_id.
+template <bool COUNT>
+__device__ __forceinline__ int32_t cast_ray(const SceneView &sv, V3 o, V3 d, Stack qs, uint32_t q, bool any_hit, bool active,
+                                            int32_t &best_tri, bool &redo, KdCounters &cnt) {
+    double bd = DBL_MAX;
+    uint32_t bs = 0xffffffffu;
+    best_tri = -1;
+    bool meshes = false;
+    // analytic shapes, one per lane and pass; the earlier node wins exact distance ties (Scene.cpp:225)
+    for (uint32_t s0 = 0; s0 < sv.n_shapes; s0 += 4) {
+        const uint32_t s = s0 + q;
+        if (!active || s >= sv.n_shapes) continue;
+        const rthip_shape &sh = sv.shapes[s];
+        const int32_t type = sh.type;
+        if (type == RTHIP_SHAPE_MESH) {
+            meshes = true;
+            continue;
+        }
+        if (COUNT) cnt.shapes++;
+        V3 lo = xform(sh.inv, o, 1.0);
+        V3 ld = normalized(xform(sh.inv, d, 0.0));
+        V3 p;
+        bool hit = type == RTHIP_SHAPE_SPHERE ? sphere_intersect(lo, ld, p)
+                                              : plane_intersect(mk(sh.plane_n[0], sh.plane_n[1], sh.plane_n[2]), lo, ld, p);
+        if (!hit) continue;
+        V3 worldPoint = xform(sh.fwd, p, 1.0);
+        double distance = sqlen(sub(o, worldPoint));
+        if (!(distance >= DBL_EPSILON)) continue;
+        if (!(distance < bd)) continue;
+        bd = distance;
+        bs = s;
+    }
+    reduce_min(bd, bs);
+    {
+        uint32_t mm = meshes ? 1u : 0u;
+        mm |= dpp<kXor1>(mm);
+        mm |= dpp<kXor2>(mm);
+        meshes = mm != 0;
+    }
+    if (!meshes) return (int32_t)bs;
+    // meshes, one after the other, all four lanes together (the shape index is wave-uniform: scalar loads)
+    for (uint32_t s = 0; s < sv.n_shapes; s++) {
+        const rt_uniform_shape *sh = rt_uniform_cast(sv.shapes) + s;
+        if (sh->type != RTHIP_SHAPE_MESH) continue;
+        if (!active || redo || (any_hit && bs != 0xffffffffu)) continue;
+        if (COUNT) cnt.shapes += (q == 0);
+        double inv[12], fwd[12];
+#pragma unroll
+        for (int k = 0; k < 12; k++) {
+            inv[k] = sh->inv[k];
+            fwd[k] = sh->fwd[k];
+        }
+        V3 lo = xform(inv, o, 1.0);
+        V3 ld = normalized(xform(inv, d, 0.0));
+        const rthip_mesh m = rt_load_mesh(sv.meshes + sh->mesh);
+        if (kd_degenerate_ray(sv, m, lo, ld)) {
+            redo = true;
+            continue;
+        }
+        const float t_stop = any_hit ? anyhit_t_stop(fwd, sh->rt_lin, sh->rt_t, o, ld) : 3.0e38f;
+        TriBest tb;
+        bool overflow = false;
+        mesh_closest<COUNT>(sv, m, lo, ld, qs, q, t_stop, tb, overflow, cnt);
+        if (overflow) {
+            redo = true;
+            continue;
+        }
+        if (!tb.hit) continue;
+        V3 p;
+        double u, v, w;
+        tri_point(sv.tris[m.tri_base + tb.tri], lo, ld, p, u, v, w);
+        V3 worldPoint = xform(fwd, p, 1.0);
+        double distance = sqlen(sub(o, worldPoint));
+        if (!(distance >= DBL_EPSILON)) continue;
+        if (distance < bd || (distance == bd && s < bs)) {
+            bd = distance;
+            bs = s;
+            best_tri = (int32_t)tb.tri;
+        }
+    }
+    return (int32_t)bs;
+}
+
+// rtc::trace_stage for the quad's ray
+template <bool COUNT>
+__device__ __forceinline__ bool trace_stage(const SceneView &sv, V3 o, V3 d, uint32_t n_shadow_lights, Stack qs, uint32_t q,
+                                            bool live, HitRec &h, KdCounters &cnt) {
+    bool redo = false;
+    h.shape = -1;
+    h.tri = -1;
+    h.shadow_mask = 0;
+    h.local = h.normal = mk(0, 0, 0);
+    V3 point = mk(0, 0, 0);
+    for (int32_t l = -1; l < (int32_t)n_shadow_lights; l++) {
+        V3 ro = o, rd = d;
+        bool active = live && !redo;
+        if (l >= 0) {
+            const rt_uniform_light *light = rt_uniform_cast(sv.lights) + l;
+            const int32_t ltype = light->type;
+            if (!light->enabled || ltype == RTHIP_LIGHT_AMBIENT) continue;  // Raytracer.cpp:213, 234-237
+            active = active && h.shape >= 0;
+            ro = point;
+            if (ltype == RTHIP_LIGHT_DIRECTIONAL)
+                rd = mk(light->direction[0], light->direction[1], light->direction[2]);
+            else
+                rd = normalized(sub(mk(light->position[0], light->position[1], light->position[2]), point));
+        }
+        int32_t tri;
+        const int32_t shape = cast_ray<COUNT>(sv, ro, rd, qs, q, l >= 0, active, tri, redo, cnt);
+        if (l < 0) {
+            if (shape >= 0 && !redo) {
+                Hit c;
+                hit_details(sv, o, d, shape, tri, c, (COUNT && q == 0) ? &cnt : nullptr);
+                h.shape = shape;
+                h.tri = tri;
+                h.local = c.local;
+                h.normal = c.normal;
+                point = c.point;
+            }
+        } else if (shape >= 0) {
+            h.shadow_mask |= 1u << l;
+        }
+    }
+    return !redo;
+}
+}  // namespace quad
+
+// ---------------------------------------------------------------------------- easy rays
+// Stage 1a of a level for the BVH path (accel = 0), one ray per lane: every query of the ray over the
+// analytic shapes, and for each mesh only a conservative test of the ray against the four root boxes
+// of its BVH.  A ray none of whose queries can touch a mesh is finished here (most of a frame: sky,
+// ground plane, spheres) in a kernel with no divergent loop at all; the others are listed, compacted
+// with a wave ballot + one atomic per wave, for the quad kernel, which traces them from scratch.
+namespace easy {
+// could the ray (local frame) hit any triangle of the mesh?  fp32, conservative (see rtc::bvh_slab)
+__device__ __forceinline__ bool mesh_may_hit(const SceneView &sv, const rthip_mesh &m, V3 lo, V3 ld) {
+    if (m.bvh_node_count == 0) return false;
+    const BvhRay r = bvh_ray(lo, ld, m.abs_max);
+    typedef const __attribute__((address_space(4))) rthip_bvhnode uniform_node;
+    uniform_node *nd = (uniform_node *)(sv.bvh_nodes + m.bvh_node_base);  // the root: wave-uniform address
+    bool any = false;
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const float blo[3] = {nd->c[c].lo[0], nd->c[c].lo[1], nd->c[c].lo[2]};
+        const float bhi[3] = {nd->c[c].hi[0], nd->c[c].hi[1], nd->c[c].hi[2]};
+        float tn;
+        bool h;
+        bvh_slab(blo, bhi, r, 3.0e38f, tn, h);
+        any = any || (h && nd->c[c].child != RTHIP_BVH_ABSENT);
+    }
+    return any;
+}
+
+// rtc::cast_ray_id restricted to the analytic shapes; `hard` is set when a mesh would have to be walked
+template <bool COUNT>
+__device__ __forceinline__ int32_t cast_ray(const SceneView &sv, V3 o, V3 d, bool any_hit, bool active, bool &hard, KdCounters &cnt) {
+    int32_t best = -1;
+    double hitDistance = DBL_MAX;
+    bool mesh_box = false;
+    for (uint32_t s = 0; s < sv.n_shapes; s++) {
+        const rt_uniform_shape *sh = rt_uniform_cast(sv.shapes) + s;
+        if (!active) continue;
+        if (COUNT) cnt.shapes++;
+        double inv[12];
+#pragma unroll
+        for (int k = 0; k < 12; k++) inv[k] = sh->inv[k];
+        const int32_t type = sh->type;
+        V3 lo = xform(inv, o, 1.0);
+        V3 ld = normalized(xform(inv, d, 0.0));
+        if (type == RTHIP_SHAPE_MESH) {
+            if (!mesh_box) mesh_box = mesh_may_hit(sv, rt_load_mesh(sv.meshes + sh->mesh), lo, ld);
+            continue;
+        }
+        V3 p;
+        const bool hit = type == RTHIP_SHAPE_SPHERE ? sphere_intersect(lo, ld, p)
+                                                    : plane_intersect(mk(sh->plane_n[0], sh->plane_n[1], sh->plane_n[2]), lo, ld, p);
+        if (!hit) continue;
+        double fwd[12];
+#pragma unroll
+        for (int k = 0; k < 12; k++) fwd[k] = sh->fwd[k];
+        V3 worldPoint = xform(fwd, p, 1.0);
+        double distance = sqlen(sub(o, worldPoint));
+        if (!(distance >= DBL_EPSILON)) continue;
+        if (!(distance < hitDistance)) continue;
+        hitDistance = distance;
+        best = (int32_t)s;
+    }
+    // an any-hit query already answered by an analytic shape does not need the mesh (only .Hit is consumed)
+    if (mesh_box && !(any_hit && best >= 0)) hard = true;
+    return best;
+}
+
+template <bool COUNT>
+__device__ __forceinline__ bool trace_stage(const SceneView &sv, V3 o, V3 d, uint32_t n_shadow_lights, bool live, HitRec &h,
+                                            KdCounters &cnt) {
+    bool hard = false;
+    h.shape = -1;
+    h.tri = -1;
+    h.shadow_mask = 0;
+    h.local = h.normal = mk(0, 0, 0);
+    V3 point = mk(0, 0, 0);
+    for (int32_t l = -1; l < (int32_t)n_shadow_lights; l++) {
+        V3 ro = o, rd = d;
+        bool active = live && !hard;
+        if (l >= 0) {
+            const rt_uniform_light *light = rt_uniform_cast(sv.lights) + l;
+            const int32_t ltype = light->type;
+            if (!light->enabled || ltype == RTHIP_LIGHT_AMBIENT) continue;  // Raytracer.cpp:213, 234-237
+            active = active && h.shape >= 0;
+            ro = point;
+            if (ltype == RTHIP_LIGHT_DIRECTIONAL)
+                rd = mk(light->direction[0], light->direction[1], light->direction[2]);
+            else
+                rd = normalized(sub(mk(light->position[0], light->position[1], light->position[2]), point));
+        }
+        const int32_t shape = cast_ray<COUNT>(sv, ro, rd, l >= 0, active, hard, cnt);
+        if (l < 0) {
+            if (shape >= 0 && !hard) {
+                Hit c;
+                hit_details(sv, o, d, shape, -1, c, nullptr);  // an analytic shape: no triangle
+                h.shape = shape;
+                h.local = c.local;
+                h.normal = c.normal;
+                point = c.point;
+            }
+        } else if (shape >= 0) {
+            h.shadow_mask |= 1u << l;
+        }
+    }
+    return !hard;
+}
+}  // namespace easy
+
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock, RT_TRACE_OCC) void k_trace_easy(SceneView sv, FrameParams fp, Work w, uint32_t level) {
+    const uint32_t n = (level == 0) ? fp.N0 : w.counts[level];
+    const uint32_t n_shadow = fp.renderer == RTHIP_RENDER_RAYTRACER ? sv.n_lights : 0u;  // DebugRaycaster: closest hit only
+    const uint32_t lane = threadIdx.x & 63u;
+    KdCounters kc = {0, 0, 0, 0, 0, 0, 0, 0};
+    const long long t_start = COUNT ? clock64() : 0;
+    for (uint32_t base = blockIdx.x * kBlock; base < n; base += gridDim.x * kBlock) {
+        const uint32_t j = base + threadIdx.x;
+        bool live = j < n;
+        const uint32_t i = live ? j : 0u;
+        V3 o = mk(0, 0, 0), d = mk(0, 0, 1);
+        uint32_t pix_slot = 0;
+        if (level == 0) {
+            uint32_t s = i / fp.n_pix_slots;  // SSAA sub-sample (0 when aa is off)
+            pix_slot = i - s * fp.n_pix_slots;
+            uint32_t x = 0, y = 0;
+            if (live && !slot_to_pixel(fp, pix_slot, x, y)) {
+                store_no_ray(w, i);  // slot outside the image
+                live = false;
+            }
+            double fx = (double)x, fy = (double)y;
+            if (fp.aa) {  // Raytracer.cpp:134-138: dx outer, dy inner, offsets +-0.5
+                int dx = (int)(s / 3) - 1, dy = (int)(s % 3) - 1;
+                fx = (double)((float)x + (float)dx * .5f);
+                fy = (double)((float)(int)y + (float)dy * .5f);
+            }
+            screen_ray(fp.cam, fp.W, fp.H, fx, fy, o, d);
+            if (live) {
+                store_ray(w, 0, i, o, d, 0u);  // the shade stage needs the direction (background, reflection)
+            }
+        } else if (live) {
+            const RayRec r = ray_at(w, level, i);
+            o = mk(r.ox, r.oy, r.oz);
+            d = mk(r.dx, r.dy, r.dz);
+        }
+        HitRec h;
+        const bool done = easy::trace_stage<COUNT>(sv, o, d, n_shadow, live, h, kc);
+        // hard rays -> list (one atomic per wave)
+        const bool is_hard = live && !done;
+        const unsigned long long mask = __ballot(is_hard);
+        if (mask) {
+            uint32_t wave_base = 0;
+            if (lane == (uint32_t)(__ffsll((long long)mask) - 1)) wave_base = atomicAdd(&w.hard_count[0], (uint32_t)__popcll(mask));
+            wave_base = __shfl(wave_base, __ffsll((long long)mask) - 1, 64);
+            if (is_hard) w.hard[wave_base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = i;
+        }
+        if (!live || !done) continue;
+        store_hit(w, i, h);
+        if (level == 0 && w.id_shape && i / fp.n_pix_slots == (fp.aa ? 4u : 0u)) {
+            w.id_shape[pix_slot] = h.shape;
+            w.id_tri[pix_slot] = -1;
+        }
+    }
+    if (COUNT) trace_counters_flush(fp, w, kc, 0, t_start);
+}
+
+// Stage 1b of a level for the BVH path (accel = 0): the rays k_trace_easy listed as needing a mesh walk,
+// four lanes per ray, see namespace quad.  Rays the quad walk cannot finish (degenerate (ray, mesh) pairs,
+// stack overflow) go to the redo list and are re-traced by k_trace<false, true>.
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock, RT_QUAD_OCC) void k_trace_quad(SceneView sv, FrameParams fp, Work w, uint32_t level) {
+    const uint32_t q = threadIdx.x & 3u, g = threadIdx.x >> 2;
+    quad::Stack qs;
+    qs.w = lds_dyn + g * quad::kStride;
+    qs.t = reinterpret_cast<float *>(lds_dyn + quad::kRaysPerBlock * quad::kStride) + g * quad::kStride;
+    const uint32_t n = w.hard_count[0];
+    const uint32_t n_shadow = fp.renderer == RTHIP_RENDER_RAYTRACER ? sv.n_lights : 0u;  // DebugRaycaster: closest hit only
+    KdCounters kc = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t max_ray_nodes = 0;
+    const long long t_start = COUNT ? clock64() : 0;
+    for (uint32_t base = blockIdx.x * quad::kRaysPerBlock; base < n; base += gridDim.x * quad::kRaysPerBlock) {
+        const uint32_t j = base + g;
+        bool live = j < n;
+        const uint32_t i = live ? w.hard[j] : 0u;
+        const uint32_t nodes_before = kc.nodes;
+        V3 o = mk(0, 0, 0), d = mk(0, 0, 1);
+        uint32_t pix_slot = 0;
+        if (level == 0) {
+            uint32_t s = i / fp.n_pix_slots;  // SSAA sub-sample (0 when aa is off)
+            pix_slot = i - s * fp.n_pix_slots;
+            uint32_t x = 0, y = 0;
+            if (live) slot_to_pixel(fp, pix_slot, x, y);  // inside the image: the easy kernel listed it
+            double fx = (double)x, fy = (double)y;
+            if (fp.aa) {  // Raytracer.cpp:134-138: dx outer, dy inner, offsets +-0.5
+                int dx = (int)(s / 3) - 1, dy = (int)(s % 3) - 1;
+                fx = (double)((float)x + (float)dx * .5f);
+                fy = (double)((float)(int)y + (float)dy * .5f);
+            }
+            screen_ray(fp.cam, fp.W, fp.H, fx, fy, o, d);  // bit-identical to the easy kernel's ray, whose direction is already stored
+        } else if (live) {
+            const RayRec r = ray_at(w, level, i);
+            o = mk(r.ox, r.oy, r.oz);
+            d = mk(r.dx, r.dy, r.dz);
+        }
+        HitRec h;
+        const bool done = quad::trace_stage<COUNT>(sv, o, d, n_shadow, qs, q, live, h, kc);
+        if (!live || q != 0) continue;
+        if (COUNT && kc.nodes - nodes_before > max_ray_nodes) max_ray_nodes = kc.nodes - nodes_before;
+        if (!done) {
+            w.redo[atomicAdd(&w.redo_count[0], 1u)] = i;
+            continue;
+        }
+        store_hit(w, i, h);
+        if (level == 0 && w.id_shape && i / fp.n_pix_slots == (fp.aa ? 4u : 0u)) {
+            w.id_shape[pix_slot] = h.shape;
+            w.id_tri[pix_slot] = h.tri;
+        }
+    }
+    if (COUNT) trace_counters_flush(fp, w, kc, max_ray_nodes, t_start);
 }
 
 // Stage 2 of a level: material / noise / background, Lambert terms with the shadow mask, and the
@@ -278,29 +814,29 @@ __global__ __launch_bounds__(kBlock, RT_SHADE_OCC) void k_shade(SceneView sv, Fr
         ShadeOut so;
         so.spawn = false;
         so.shadow_rays = 0;
-        int32_t shape = i < n ? w.hit_shape[i] : -2;
+        HitSlot hs;
+        hs.shape = -2;
+        if (i < n) hs = w.hit[i];
+        const int32_t shape = hs.shape;
         if (shape > -2) {
             HitRec h;
             h.shape = shape;
             h.tri = -1;
-            h.shadow_mask = 0;
-            h.local = h.normal = mk(0, 0, 0);
-            V3 d = mk(ray_ptr(w, level, 3)[i], ray_ptr(w, level, 4)[i], ray_ptr(w, level, 5)[i]);
-            if (shape >= 0) {
-                h.shadow_mask = w.hit_mask[i];
-                h.local = mk(hit_ptr(w, 0)[i], hit_ptr(w, 1)[i], hit_ptr(w, 2)[i]);
-                h.normal = mk(hit_ptr(w, 3)[i], hit_ptr(w, 4)[i], hit_ptr(w, 5)[i]);
-            }
+            h.shadow_mask = hs.mask;
+            h.local = mk(hs.lx, hs.ly, hs.lz);
+            h.normal = mk(hs.nx, hs.ny, hs.nz);
+            const RayRec rr = ray_at(w, level, i);
+            V3 d = mk(rr.dx, rr.dy, rr.dz);
             if (fp.renderer == RTHIP_RENDER_RAYTRACER) {
                 shade_stage(sv, tabs, h, d, level < fp.max_rec, so);
             } else {
                 so.color = debug_shade(sv, tabs, h, d, fp.renderer - 1);
                 so.refl = 0.0;
             }
-            rec_ptr(w, level, 0)[i] = so.color.r;
-            rec_ptr(w, level, 1)[i] = so.color.g;
-            rec_ptr(w, level, 2)[i] = so.color.b;
-            rec_ptr(w, level, 3)[i] = so.refl;
+            ColRec cr;
+            cr.r = so.color.r; cr.g = so.color.g; cr.b = so.color.b; cr.refl = so.refl;
+            rec_at(w, level, i) = cr;
+            if (level > 0) w.parent[(size_t)level * w.N + i] = rr.parent;  // for k_fold; full-line store (all lanes, in order)
         }
         // compaction of the reflected rays
         unsigned long long mask = __ballot(so.spawn);
@@ -314,23 +850,28 @@ __global__ __launch_bounds__(kBlock, RT_SHADE_OCC) void k_shade(SceneView sv, Fr
         if (so.spawn) {
             uint32_t j = block_base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
             for (uint32_t k = 0; k < wid; k++) j += wave_cnt[k];
-            ray_ptr(w, level + 1, 0)[j] = so.child_o.x;
-            ray_ptr(w, level + 1, 1)[j] = so.child_o.y;
-            ray_ptr(w, level + 1, 2)[j] = so.child_o.z;
-            ray_ptr(w, level + 1, 3)[j] = so.child_d.x;
-            ray_ptr(w, level + 1, 4)[j] = so.child_d.y;
-            ray_ptr(w, level + 1, 5)[j] = so.child_d.z;
-            w.parent[(size_t)(level + 1) * w.N + j] = i;
+            store_ray(w, level + 1, j, so.child_o, so.child_d, i);
             spawn_total++;
         }
         shadow_total += so.shadow_rays;
         __syncthreads();  // wave_cnt / block_base are reused by the next chunk
     }
+    // ray statistics without atomics (32 K same-address atomics cost more than the whole shading):
+    // one plain read-modify-write per workgroup into its own slot, summed on the host on demand
     shadow_total = wave_sum(shadow_total);
     spawn_total = wave_sum(spawn_total);
+    __shared__ uint32_t part[2][kBlock / 64];
     if (lane == 0) {
-        if (shadow_total) atomicAdd(&w.stats[ST_SHADOW], (unsigned long long)shadow_total);
-        if (spawn_total) atomicAdd(&w.stats[ST_REFLECT], (unsigned long long)spawn_total);
+        part[0][wid] = shadow_total;
+        part[1][wid] = spawn_total;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint2 *slot = w.block_stats + (size_t)level * w.bs_stride + blockIdx.x;
+        uint2 v = *slot;
+        v.x += part[0][0] + part[0][1] + part[0][2] + part[0][3];
+        v.y += part[1][0] + part[1][1] + part[1][2] + part[1][3];
+        *slot = v;
     }
 }
 
@@ -339,12 +880,11 @@ __global__ __launch_bounds__(kBlock) void k_fold(Work w, uint32_t level) {
     const uint32_t n = w.counts[level];
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
         uint32_t p = w.parent[(size_t)level * w.N + i];
-        Col child = Col{rec_ptr(w, level, 0)[i], rec_ptr(w, level, 1)[i], rec_ptr(w, level, 2)[i]};
-        Col direct = Col{rec_ptr(w, level - 1, 0)[p], rec_ptr(w, level - 1, 1)[p], rec_ptr(w, level - 1, 2)[p]};
-        Col c = fold(direct, child, rec_ptr(w, level - 1, 3)[p]);
-        rec_ptr(w, level - 1, 0)[p] = c.r;
-        rec_ptr(w, level - 1, 1)[p] = c.g;
-        rec_ptr(w, level - 1, 2)[p] = c.b;
+        const ColRec ch = rec_at(w, level, i);
+        ColRec pr = rec_at(w, level - 1, p);
+        Col c = fold(Col{pr.r, pr.g, pr.b}, Col{ch.r, ch.g, ch.b}, pr.refl);
+        pr.r = c.r; pr.g = c.g; pr.b = c.b;
+        rec_at(w, level - 1, p) = pr;
     }
 }
 
@@ -361,11 +901,13 @@ __global__ __launch_bounds__(kBlock) void k_resolve(FrameParams fp, Work w, uint
         const double k = (double)(1.0f / 9.0f);
         for (uint32_t s = 0; s < 9; s++) {
             size_t i = (size_t)s * fp.n_pix_slots + ps;
-            Col r = Col{rec_ptr(w, 0, 0)[i], rec_ptr(w, 0, 1)[i], rec_ptr(w, 0, 2)[i]};
+            const ColRec q = rec_at(w, 0, (uint32_t)i);
+            Col r = Col{q.r, q.g, q.b};
             c = c_add(c, c_scale(r, k));
         }
     } else {
-        c = Col{rec_ptr(w, 0, 0)[ps], rec_ptr(w, 0, 1)[ps], rec_ptr(w, 0, 2)[ps]};
+        const ColRec q = rec_at(w, 0, ps);
+        c = Col{q.r, q.g, q.b};
     }
     size_t idx = fp.layout ? (size_t)fp.q0 * fp.tile_w * fp.tile_h + ps : (size_t)y * fp.W + x;
     pixels[idx] = c_pack(c);
@@ -462,7 +1004,8 @@ struct rthip_ctx {
     bool has_scene = false;
     uint32_t stack_cap = 1;
     // frame workspace
-    DevBuf rec, parent, rays, counts, stats, ids, pixels_tmp, ids_out, hits, hit_ids, redo, probe[8];
+    DevBuf rec, parent, rays, counts, stats, block_stats, ids, pixels_tmp, ids_out, hits, redo, probe[8];
+    uint32_t bs_stride = 0, bs_levels = 0;
     uint32_t n_tables = 0;
     bool has_meshes = false;
     std::atomic<int> interrupt{0};
@@ -514,7 +1057,7 @@ int rthip_destroy(rthip_ctx *c) {
     (void)hipStreamSynchronize(c->stream);
     DevBuf *all[] = {&c->shapes, &c->meshes, &c->kd_nodes, &c->kd_bounds, &c->kd_refs, &c->tris, &c->tri_normals,
                      &c->materials, &c->noises, &c->perlin, &c->worley, &c->lights, &c->rec, &c->parent, &c->rays,
-                     &c->counts, &c->stats, &c->ids, &c->pixels_tmp, &c->ids_out, &c->bvh_nodes, &c->bvh_tris, &c->bvh_index, &c->kd_planes, &c->hits, &c->hit_ids, &c->redo};
+                     &c->counts, &c->stats, &c->ids, &c->pixels_tmp, &c->ids_out, &c->bvh_nodes, &c->bvh_tris, &c->bvh_index, &c->kd_planes, &c->hits, &c->redo, &c->block_stats};
     for (DevBuf *b : all) b->release();
     for (DevBuf &b : c->probe) b.release();
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
@@ -613,13 +1156,13 @@ static int validate_scene(const rthip_scene_desc *s, uint32_t *max_depth, uint32
         if (!(m.abs_max >= 0.0f)) BAD("mesh %u: abs_max", i);
         for (uint32_t k = 0; k < m.bvh_node_count; k++) {
             const rthip_bvhnode &nd = s->bvh_nodes[m.bvh_node_base + k];
-            const uint32_t ch[2] = {nd.child0, nd.child1};
-            for (int c = 0; c < 2; c++) {
-                if (ch[c] & RTHIP_BVH_LEAF) {
-                    bool absent = c == 1 ? !(nd.lo1[0] <= nd.hi1[0]) : !(nd.lo0[0] <= nd.hi0[0]);
-                    uint64_t first = ch[c] & RTHIP_BVH_FIRST_MASK, cnt = ((ch[c] >> RTHIP_BVH_COUNT_SHIFT) & 7u) + 1u;
-                    if (!absent && first + cnt > m.tri_count) BAD("mesh %u bvh node %u: leaf out of range", i, k);
-                } else if (ch[c] >= m.bvh_node_count || ch[c] <= k) {
+            for (int c = 0; c < 4; c++) {
+                const uint32_t w = nd.c[c].child;
+                if (w == RTHIP_BVH_ABSENT) continue;
+                if (w & RTHIP_BVH_LEAF) {
+                    uint64_t first = w & RTHIP_BVH_FIRST_MASK, cnt = ((w >> RTHIP_BVH_COUNT_SHIFT) & 7u) + 1u;
+                    if (cnt > RTHIP_BVH_MAX_LEAF || first + cnt > m.tri_count) BAD("mesh %u bvh node %u: leaf out of range", i, k);
+                } else if (w >= m.bvh_node_count || w <= k) {
                     BAD("mesh %u bvh node %u: child out of range", i, k);
                 }
             }
@@ -705,8 +1248,8 @@ int rthip_upload_scene(rthip_ctx *c, const rthip_scene_desc *s) {
     c->has_meshes = s->n_meshes > 0;
     v.bg = s->background;
     c->stack_cap_kd = max_depth + 2;
-    c->stack_cap_bvh = max_bvh_depth + 2;
-    c->stack_cap_full = (max_depth > max_bvh_depth ? max_depth : max_bvh_depth) + 2;  // degenerate rays walk the kd-tree
+    c->stack_cap_bvh = 3 * max_bvh_depth + 2;  // one ray per lane over the 4-wide BVH: up to three pending children per level
+    c->stack_cap_full = (max_depth + 2 > c->stack_cap_bvh ? max_depth + 2 : c->stack_cap_bvh);  // degenerate rays walk the kd-tree
     c->stack_cap = c->stack_cap_full;
     c->has_scene = true;
     return 0;
@@ -765,27 +1308,30 @@ static int render_frame(rthip_ctx *c, const rthip_camera *cam, const rthip_param
     if (tiles_per_chunk > my_tiles) tiles_per_chunk = my_tiles ? my_tiles : 1;
     const size_t N = (size_t)tiles_per_chunk * per_tile * spp;
 
-    if (c->rec.ensure(sizeof(double) * 4 * N * levels)) return RTHIP_E_HIP;
+    if (c->rec.ensure(sizeof(ColRec) * N * levels)) return RTHIP_E_HIP;
     if (c->parent.ensure(sizeof(uint32_t) * N * levels)) return RTHIP_E_HIP;
-    if (c->rays.ensure(sizeof(double) * 12 * N)) return RTHIP_E_HIP;
-    if (c->counts.ensure(sizeof(uint32_t) * 2 * (RTHIP_MAX_RECURSION + 3))) return RTHIP_E_HIP;
+    if (c->rays.ensure(sizeof(RayRec) * 2 * N)) return RTHIP_E_HIP;
+    if (c->counts.ensure(sizeof(uint32_t) * 3 * (RTHIP_MAX_RECURSION + 3))) return RTHIP_E_HIP;
     if (c->stats.ensure(sizeof(unsigned long long) * ST_COUNT)) return RTHIP_E_HIP;
+    c->bs_stride = (uint32_t)((N + kBlock - 1) / kBlock);
+    c->bs_levels = levels;
+    if (c->block_stats.ensure(sizeof(uint2) * (size_t)c->bs_stride * levels)) return RTHIP_E_HIP;
     if (c->ids.ensure(sizeof(int32_t) * 2 * (size_t)tiles_per_chunk * per_tile)) return RTHIP_E_HIP;
-    if (c->hits.ensure(sizeof(double) * 6 * N)) return RTHIP_E_HIP;
-    if (c->hit_ids.ensure(sizeof(uint32_t) * 2 * N)) return RTHIP_E_HIP;
-    if (c->redo.ensure(sizeof(uint32_t) * N)) return RTHIP_E_HIP;
+    if (c->hits.ensure(sizeof(HitSlot) * N)) return RTHIP_E_HIP;
+    if (c->redo.ensure(sizeof(uint32_t) * 2 * N)) return RTHIP_E_HIP;
     Work w;
-    w.rec = (double *)c->rec.p;
+    w.rec = (ColRec *)c->rec.p;
     w.parent = (uint32_t *)c->parent.p;
-    w.rays = (double *)c->rays.p;
+    w.rays = (RayRec *)c->rays.p;
     w.counts = (uint32_t *)c->counts.p;
     w.stats = (unsigned long long *)c->stats.p;
     w.id_shape = (d_shape || d_tri) ? (int32_t *)c->ids.p : nullptr;
     w.id_tri = w.id_shape ? w.id_shape + (size_t)tiles_per_chunk * per_tile : nullptr;
-    w.hit = (double *)c->hits.p;
-    w.hit_shape = (int32_t *)c->hit_ids.p;
-    w.hit_mask = (uint32_t *)c->hit_ids.p + N;
+    w.hit = (HitSlot *)c->hits.p;
     w.redo = (uint32_t *)c->redo.p;
+    w.hard = w.redo + N;
+    w.block_stats = (uint2 *)c->block_stats.p;
+    w.bs_stride = c->bs_stride;
     w.N = (uint32_t)N;
 
     c->sv.accel = p->accel;
@@ -798,12 +1344,12 @@ static int render_frame(rthip_ctx *c, const rthip_camera *cam, const rthip_param
         HIP_TRY(hipFuncSetAttribute((const void *)k_trace<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
         HIP_TRY(hipFuncSetAttribute((const void *)k_trace<false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     }
-    // hot kernel: short stack (child word + entry parameter per entry); deeper rays overflow into the redo list
-    const uint32_t cap_fast = c->stack_cap_bvh < kFastStackCap ? c->stack_cap_bvh : kFastStackCap;
-    const size_t lds_fast = (size_t)cap_fast * kBlock * sizeof(uint32_t) * 2;
+    // hot kernel: one short stack per quad (child word + entry parameter per entry); deeper rays overflow into the redo list
+    const size_t lds_quad = (size_t)quad::kRaysPerBlock * quad::kStride * sizeof(uint32_t) * 2;
     const size_t lds_tables = (size_t)c->n_tables * 256;
 
     HIP_TRY(hipMemsetAsync(w.stats, 0, sizeof(unsigned long long) * ST_COUNT, c->stream));
+    HIP_TRY(hipMemsetAsync(w.block_stats, 0, sizeof(uint2) * (size_t)c->bs_stride * levels, c->stream));
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
     size_t ev_used = 0;
     auto get_event = [&](hipEvent_t *e) -> int {
@@ -823,21 +1369,30 @@ static int render_frame(rthip_ctx *c, const rthip_camera *cam, const rthip_param
         fp.q0 = q0;
         fp.n_pix_slots = nq * per_tile;
         fp.N0 = fp.n_pix_slots * spp;
-        HIP_TRY(hipMemsetAsync(w.counts, 0, sizeof(uint32_t) * 2 * (RTHIP_MAX_RECURSION + 3), c->stream));
+        HIP_TRY(hipMemsetAsync(w.counts, 0, sizeof(uint32_t) * 3 * (RTHIP_MAX_RECURSION + 3), c->stream));
         for (uint32_t level = 0; level < levels; level++) {
             uint32_t grid = (fp.N0 + kBlock - 1) / kBlock;
             if (level > 0 && grid > kMaxGridLevel) grid = kMaxGridLevel;
-            hipEvent_t ea = nullptr, eb = nullptr;
+            hipEvent_t ea = nullptr, eb = nullptr, ec = nullptr;
             if (c->profile_launches) {
-                if (get_event(&ea) || get_event(&eb)) return RTHIP_E_HIP;
+                if (get_event(&ea) || get_event(&eb) || get_event(&ec)) return RTHIP_E_HIP;
                 HIP_TRY(hipEventRecord(ea, c->stream));
             }
             w.redo_count = w.counts + (RTHIP_MAX_RECURSION + 3) + level;
+            w.hard_count = w.counts + 2 * (RTHIP_MAX_RECURSION + 3) + level;
             if (p->accel == 0) {
                 if (c->count_kd)
-                    hipLaunchKernelGGL((k_trace<true, false, true>), dim3(grid), dim3(kBlock), lds_fast, c->stream, c->sv, fp, w, level, cap_fast);
+                    hipLaunchKernelGGL((k_trace_easy<true>), dim3(grid), dim3(kBlock), 0, c->stream, c->sv, fp, w, level);
                 else
-                    hipLaunchKernelGGL((k_trace<true, false, false>), dim3(grid), dim3(kBlock), lds_fast, c->stream, c->sv, fp, w, level, cap_fast);
+                    hipLaunchKernelGGL((k_trace_easy<false>), dim3(grid), dim3(kBlock), 0, c->stream, c->sv, fp, w, level);
+                if (c->has_meshes) {  // the rays that need a mesh walk (count on the device: the grid is an upper bound, strided)
+                    uint32_t qgrid = (fp.N0 + quad::kRaysPerBlock - 1) / quad::kRaysPerBlock;
+                    if (qgrid > kMaxGridQuad) qgrid = kMaxGridQuad;
+                    if (c->count_kd)
+                        hipLaunchKernelGGL((k_trace_quad<true>), dim3(qgrid), dim3(kBlock), lds_quad, c->stream, c->sv, fp, w, level);
+                    else
+                        hipLaunchKernelGGL((k_trace_quad<false>), dim3(qgrid), dim3(kBlock), lds_quad, c->stream, c->sv, fp, w, level);
+                }
                 if (c->profile_launches) HIP_TRY(hipEventRecord(eb, c->stream));
                 if (c->has_meshes) {  // re-trace of the (rare) rays lying exactly in a kd split plane or overflowing the short stack
                     if (c->count_kd)
@@ -853,6 +1408,7 @@ static int render_frame(rthip_ctx *c, const rthip_camera *cam, const rthip_param
                 if (c->profile_launches) HIP_TRY(hipEventRecord(eb, c->stream));
             }
             hipLaunchKernelGGL(k_shade, dim3(grid), dim3(kBlock), lds_tables, c->stream, c->sv, fp, w, level, c->n_tables);
+            if (c->profile_launches) HIP_TRY(hipEventRecord(ec, c->stream));
         }
         for (uint32_t level = levels - 1; level >= 1; level--) {
             uint32_t grid = (fp.N0 + kBlock - 1) / kBlock;
@@ -874,7 +1430,7 @@ static int render_frame(rthip_ctx *c, const rthip_camera *cam, const rthip_param
         HIP_TRY(hipStreamSynchronize(c->stream));
         return fail(RTHIP_E_INTERRUPTED, "rthip_render: interrupted");
     }
-    c->last.launches_trace = (uint32_t)(ev_used / 2);
+    c->last.launches_trace = (uint32_t)(ev_used / 3);
     return 0;
 }
 
@@ -896,8 +1452,14 @@ static int finish_stats(rthip_ctx *c, const rthip_params *p) {
     }
     c->last.pixels = px;
     c->last.rays_primary = px * (p->aa_mode ? 9 : 1);
-    c->last.rays_shadow = st[ST_SHADOW];
-    c->last.rays_reflect = st[ST_REFLECT];
+    {
+        std::vector<uint2> parts((size_t)c->bs_stride * c->bs_levels);
+        if (!parts.empty()) HIP_TRY(hipMemcpy(parts.data(), c->block_stats.p, sizeof(uint2) * parts.size(), hipMemcpyDeviceToHost));
+        uint64_t shadow = 0, reflect = 0;
+        for (const uint2 &v : parts) { shadow += v.x; reflect += v.y; }
+        c->last.rays_shadow = shadow;
+        c->last.rays_reflect = reflect;
+    }
     c->last.kd_nodes_visited = st[ST_KD_NODES];
     c->last.kd_tris_tested = st[ST_KD_TRIS];
     c->last.kd_leaves_visited = st[ST_KD_LEAVES];
@@ -913,15 +1475,20 @@ static int finish_stats(rthip_ctx *c, const rthip_params *p) {
     uint32_t lr[RTHIP_MAX_RECURSION + 1];
     HIP_TRY(hipMemcpy(lr, c->counts.p, sizeof lr, hipMemcpyDeviceToHost));
     memset(c->last.level_ms_trace, 0, sizeof c->last.level_ms_trace);
+    memset(c->last.level_ms_shade, 0, sizeof c->last.level_ms_shade);
     for (uint32_t i = 0; i <= RTHIP_MAX_RECURSION; i++) c->last.level_rays[i] = i <= p->max_recursion ? lr[i] : 0;
     c->last.level_rays[0] = (uint32_t)c->last.rays_primary;
     c->last.ms_total = ms;
     float sum = 0.f;
     for (uint32_t i = 0; i < c->last.launches_trace; i++) {
-        float t = 0.f;
-        HIP_TRY(hipEventElapsedTime(&t, c->ev_pool[2 * i], c->ev_pool[2 * i + 1]));
+        float t = 0.f, u = 0.f;
+        HIP_TRY(hipEventElapsedTime(&t, c->ev_pool[3 * i], c->ev_pool[3 * i + 1]));
+        HIP_TRY(hipEventElapsedTime(&u, c->ev_pool[3 * i + 1], c->ev_pool[3 * i + 2]));
         sum += t;
-        if (i <= RTHIP_MAX_RECURSION) c->last.level_ms_trace[i] = t;  // single-chunk frames: launch i = level i
+        if (i <= RTHIP_MAX_RECURSION) {  // single-chunk frames: launch i = level i
+            c->last.level_ms_trace[i] = t;
+            c->last.level_ms_shade[i] = u;  // includes the (normally empty) redo kernel
+        }
     }
     c->last.ms_trace = sum;
     c->progress.store(1.f);

@@ -211,7 +211,8 @@ struct KdTreeFlat {
 
 // Device-oriented BVH over the same triangles (no reference counterpart; see include/rthip.h).
 struct BvhFlat {
-    struct Node { float lo0[3], hi0[3], lo1[3], hi1[3]; uint32_t child0, child1, pad[2]; };
+    struct Child { float lo[3], hi[3]; uint32_t child, pad; };
+    struct Node { Child c[4]; };  // == rthip_bvhnode
     std::vector<Node> nodes;
     std::vector<uint32_t> order;  // leaf-order position -> triangle index
     uint32_t depth = 0;

@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 
 #include "re/scene.hpp"
 #include "rthip.h"
@@ -161,11 +162,13 @@ struct KdBuilder {
 }  // namespace
 
 namespace {
-// Binned-SAH BVH builder (16 bins, 3 axes).  Boxes are exact fp64 while building and rounded
-// OUTWARD (plus one ulp) to fp32 when stored, so the device's fp32 slab test stays conservative.
+// Binned-SAH binary BVH (16 bins, 3 axes), then collapsed to 4-wide nodes.  Boxes are exact fp64 while
+// building and rounded OUTWARD (plus one ulp) to fp32 when stored, so the device's fp32 slab test stays
+// conservative.  Leaves hold 1..4 triangles: the four lanes that trace a ray test them in one step, so a
+// group of <= 4 triangles is never split further.
 struct BvhBuilder {
     static constexpr int kBins = 16;
-    static constexpr uint32_t kMaxLeaf = 8;
+    static constexpr uint32_t kMaxLeaf = RTHIP_BVH_MAX_LEAF;
     struct Box {
         double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
         void Grow(const double *l, const double *h) {
@@ -177,9 +180,11 @@ struct BvhBuilder {
             return dx < 0 ? 0.0 : 2 * (dx * dy + dx * dz + dy * dz);
         }
     };
+    struct Node2 { Box b[2]; uint32_t c[2]; };
     const std::vector<Triangle> &tris;
     BvhFlat &out;
     std::vector<double> tlo, thi, cen;  // 3 per triangle
+    std::vector<Node2> bin;             // the binary tree
 
     static float Down(double x) {
         float f = (float)x;
@@ -212,13 +217,12 @@ struct BvhBuilder {
         for (uint32_t i = lo; i < hi; i++) b.Grow(&tlo[3 * out.order[i]], &thi[3 * out.order[i]]);
         return b;
     }
-    // builds the subtree over order[lo,hi); returns the child word and its box
+    // builds the binary subtree over order[lo,hi); returns the child word and its box
     uint32_t Build(uint32_t lo, uint32_t hi, unsigned depth, Box &box) {
         box = BoundsOf(lo, hi);
         const uint32_t n = hi - lo;
-        out.depth = std::max(out.depth, depth);
         auto leaf = [&]() { return RTHIP_BVH_LEAF | ((n - 1) << RTHIP_BVH_COUNT_SHIFT) | lo; };
-        if (n <= 1 || (n <= kMaxLeaf && depth >= RTHIP_BVH_MAX_DEPTH - 2)) return leaf();
+        if (n <= kMaxLeaf) return leaf();
         Box cb;  // centroid bounds
         for (uint32_t i = lo; i < hi; i++) cb.Grow(&cen[3 * out.order[i]], &cen[3 * out.order[i]]);
         int best_axis = -1, best_bin = 0;
@@ -249,17 +253,13 @@ struct BvhBuilder {
                 for (int b = 0; b < kBins - 1; b++) {
                     acc.Grow(bb[b]); c += cnt[b];
                     if (c == 0 || right_cnt[b + 1] == 0) continue;
-                    const double cost = acc.Area() * c + right_area[b + 1] * right_cnt[b + 1];
+                    // leaves are tested four triangles at a time: cost in units of ceil(n / 4)
+                    const double cost = acc.Area() * ((c + 3) / 4) + right_area[b + 1] * ((right_cnt[b + 1] + 3) / 4);
                     if (cost < best_cost) { best_cost = cost; best_axis = a; best_bin = b; }
                 }
             }
         }
-        // SAH says "do not split" only matters for small groups: a triangle test costs ~2.5 box steps
-        if (best_axis >= 0 && n <= 4) {
-            const double split_cost = 1.0 + 2.5 * best_cost / std::max(box.Area(), 1e-300);
-            if (split_cost >= 2.5 * n) return leaf();
-        }
-        uint32_t mid;
+        uint32_t mid = lo;
         if (best_axis >= 0) {
             const int a = best_axis;
             const double k = kBins / (cb.hi[a] - cb.lo[a]), base = cb.lo[a];
@@ -269,11 +269,8 @@ struct BvhBuilder {
                 return b <= best_bin;
             });
             mid = (uint32_t)(first_right - out.order.begin());
-        } else {
-            mid = lo;
         }
-        if (mid == lo || mid == hi) {  // coincident centroids or depth guard: median split on the widest axis
-            if (n <= kMaxLeaf && best_axis < 0 && depth < 40) return leaf();
+        if (mid == lo || mid == hi || depth >= 40) {  // coincident centroids or depth guard: median split on the widest axis
             int a = 0;
             for (int k2 = 1; k2 < 3; k2++)
                 if (cb.hi[k2] - cb.lo[k2] > cb.hi[a] - cb.lo[a]) a = k2;
@@ -281,26 +278,47 @@ struct BvhBuilder {
             std::nth_element(out.order.begin() + lo, out.order.begin() + mid, out.order.begin() + hi,
                              [&](uint32_t x, uint32_t y) { return cen[3 * x + a] < cen[3 * y + a]; });
         }
-        if (n > kMaxLeaf && depth >= RTHIP_BVH_MAX_DEPTH - 2) {  // cannot happen with median halving below 2^60 triangles
-            mid = lo + n / 2;
-        }
-        const uint32_t me = (uint32_t)out.nodes.size();
-        out.nodes.emplace_back();
+        const uint32_t me = (uint32_t)bin.size();
+        bin.emplace_back();
         Box b0, b1;
         const uint32_t c0 = Build(lo, mid, depth + 1, b0);
         const uint32_t c1 = Build(mid, hi, depth + 1, b1);
-        Fill(me, c0, b0, c1, &b1);
+        bin[me].b[0] = b0; bin[me].b[1] = b1;
+        bin[me].c[0] = c0; bin[me].c[1] = c1;
         return me;
     }
-    void Fill(uint32_t me, uint32_t c0, const Box &b0, uint32_t c1, const Box *b1) {
-        BvhFlat::Node &nd = out.nodes[me];
-        for (int a = 0; a < 3; a++) {
-            nd.lo0[a] = Down(b0.lo[a]); nd.hi0[a] = Up(b0.hi[a]);
-            nd.lo1[a] = b1 ? Down(b1->lo[a]) : INFINITY;
-            nd.hi1[a] = b1 ? Up(b1->hi[a]) : -INFINITY;
+    // 4-wide node from the binary node n2: repeatedly open the interior child with the largest box
+    uint32_t Collapse(uint32_t n2, unsigned depth) {
+        struct Item { uint32_t c; Box b; };
+        Item items[4] = {{bin[n2].c[0], bin[n2].b[0]}, {bin[n2].c[1], bin[n2].b[1]}};
+        int n = 2;
+        while (n < 4) {
+            int pick = -1;
+            double area = -1;
+            for (int i = 0; i < n; i++)
+                if (!(items[i].c & RTHIP_BVH_LEAF) && items[i].b.Area() > area) { area = items[i].b.Area(); pick = i; }
+            if (pick < 0) break;
+            const Node2 &o = bin[items[pick].c];
+            const Item a = {o.c[0], o.b[0]}, b = {o.c[1], o.b[1]};
+            items[pick] = a;
+            items[n++] = b;
         }
-        nd.child0 = c0; nd.child1 = c1;
-        nd.pad[0] = nd.pad[1] = 0;
+        const uint32_t me = (uint32_t)out.nodes.size();
+        out.nodes.emplace_back();
+        out.depth = std::max(out.depth, depth);
+        for (int i = 0; i < 4; i++) {
+            BvhFlat::Child ch;
+            std::memset(&ch, 0, sizeof ch);
+            if (i < n) {
+                for (int a = 0; a < 3; a++) { ch.lo[a] = Down(items[i].b.lo[a]); ch.hi[a] = Up(items[i].b.hi[a]); }
+                ch.child = (items[i].c & RTHIP_BVH_LEAF) ? items[i].c : Collapse(items[i].c, depth + 1);
+            } else {
+                for (int a = 0; a < 3; a++) { ch.lo[a] = INFINITY; ch.hi[a] = -INFINITY; }
+                ch.child = RTHIP_BVH_ABSENT;
+            }
+            out.nodes[me].c[i] = ch;
+        }
+        return me;
     }
     void Run() {
         out = BvhFlat();
@@ -308,10 +326,22 @@ struct BvhBuilder {
         Prepare();
         Box root;
         const uint32_t w = Build(0, (uint32_t)tris.size(), 0, root);
-        if (w & RTHIP_BVH_LEAF) {  // tiny mesh: a root node whose first child is the single leaf
+        if (w & RTHIP_BVH_LEAF) {  // tiny mesh: a root node whose only child is the single leaf
             out.nodes.emplace_back();
-            Fill(0, w, root, RTHIP_BVH_LEAF, nullptr);
+            for (int i = 0; i < 4; i++) {
+                BvhFlat::Child ch;
+                std::memset(&ch, 0, sizeof ch);
+                for (int a = 0; a < 3; a++) {
+                    ch.lo[a] = i == 0 ? Down(root.lo[a]) : INFINITY;
+                    ch.hi[a] = i == 0 ? Up(root.hi[a]) : -INFINITY;
+                }
+                ch.child = i == 0 ? w : RTHIP_BVH_ABSENT;
+                out.nodes[0].c[i] = ch;
+            }
+        } else {
+            Collapse(w, 0);
         }
+        std::vector<Node2>().swap(bin);
     }
 };
 }  // namespace
@@ -332,7 +362,7 @@ void Mesh::Compile() {
     for (size_t i = 0; i < all.size(); i++) all[i] = (uint32_t)i;
     KdBuilder builder{m_Triangles, m_KdTree};
     builder.Build(all, m_BoundingBox, 0);
-    BvhBuilder bvh{m_Triangles, m_Bvh, {}, {}, {}};
+    BvhBuilder bvh{m_Triangles, m_Bvh, {}, {}, {}, {}};
     bvh.Run();
     m_Invalidated = false;
 }

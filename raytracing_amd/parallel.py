@@ -1,5 +1,6 @@
 """Screen partition used by the multi-GPU path, restated on the host with numpy: interleaved
-tile_w x tile_h tiles (tile t -> part t % part_count), 8x8 sub-blocks inside a tile — the same
+tile_w x tile_h tiles (tile t -> part t % part_count), 8x8 sub-blocks inside a tile, four 4x4 patches
+inside a sub-block — the same
 slot order the device writes with rthip_params.layout = 1 and reads in rthip_assemble (k_assemble).
 Used by the CPU (gloo) tests and as documentation of the layout; the GPU path gathers with
 torch.distributed (RCCL) and assembles on the device."""
@@ -18,8 +19,8 @@ def _slot_xy(w, h, part, part_count, tile_w=32, tile_h=8):
     tx, ty = t % tiles_x, t // tiles_x
     sb, l = r >> 6, r & 63
     sbx = tile_w >> 3
-    x = tx * tile_w + (sb % sbx) * 8 + (l & 7)
-    y = ty * tile_h + (sb // sbx) * 8 + (l >> 3)
+    x = tx * tile_w + (sb % sbx) * 8 + ((l & 3) | ((l >> 2) & 4))
+    y = ty * tile_h + (sb // sbx) * 8 + (((l >> 2) & 3) | ((l >> 3) & 4))
     valid = (t < n_tiles) & (x < w) & (y < h)
     return x, y, valid
 

@@ -126,28 +126,33 @@ def test_bvh_is_complete_and_conservative(host_lib):
                     ("bvh_tris", C.c_void_p), ("bvh_tri_index", C.c_void_p)]
     d = Desc.from_address(desc)
     n_tris, n_nodes = d.n_tris, d.n_bvh_nodes
-    assert n_tris == 4968 and n_nodes > 1000
-    nodes = np.frombuffer((C.c_char * (64 * n_nodes)).from_address(d.bvh_nodes), dtype=np.dtype(
-        [("lo0", "<f4", 3), ("hi0", "<f4", 3), ("lo1", "<f4", 3), ("hi1", "<f4", 3), ("c0", "<u4"), ("c1", "<u4"), ("pad", "<u4", 2)]))
+    assert n_tris == 4968 and n_nodes > 300
+    child = np.dtype([("lo", "<f4", 3), ("hi", "<f4", 3), ("child", "<u4"), ("pad", "<u4")])
+    nodes = np.frombuffer((C.c_char * (128 * n_nodes)).from_address(d.bvh_nodes), dtype=np.dtype([("c", child, 4)]))
     index = np.frombuffer((C.c_uint32 * n_tris).from_address(d.bvh_tri_index), dtype=np.uint32)
     assert sorted(index.tolist()) == list(range(n_tris))            # a permutation: no triangle lost or duplicated
     verts = scenes.load_bunny()[0].reshape(-1, 3, 3)
     seen = np.zeros(n_tris, bool)
     stack = [(0, np.full(3, -np.inf), np.full(3, np.inf))]
+    visited = 0
     while stack:
         ni, lo, hi = stack.pop()
-        nd = nodes[ni]
-        for c, blo, bhi in ((nd["c0"], nd["lo0"], nd["hi0"]), (nd["c1"], nd["lo1"], nd["hi1"])):
-            if not (blo[0] <= bhi[0]):
+        visited += 1
+        for ch in nodes[ni]["c"]:
+            c, blo, bhi = int(ch["child"]), ch["lo"], ch["hi"]
+            if c == 0xffffffff:
                 continue                                            # absent child
             clo, chi = np.maximum(lo, blo.astype(np.float64)), np.minimum(hi, bhi.astype(np.float64))
             if c & 0x80000000:
-                first, cnt = int(c & 0x0fffffff), int((c >> 28) & 7) + 1
+                first, cnt = c & 0x0fffffff, ((c >> 28) & 7) + 1
+                assert cnt <= 4                                     # one triangle per lane of the quad
                 for k in range(first, first + cnt):
                     t = index[k]
                     assert not seen[t]
                     seen[t] = True
                     assert (verts[t] >= clo).all() and (verts[t] <= chi).all(), "triangle sticks out of its boxes"
             else:
-                stack.append((int(c), clo, chi))
+                assert c > ni                                       # children follow their parent
+                stack.append((c, clo, chi))
+    assert visited == n_nodes
     assert seen.all()

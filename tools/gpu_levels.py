@@ -13,7 +13,7 @@ for cfg in cfgs:
     W, H, mr = kw["width"], kw["height"], kw["max_recursion"]
     cam = hs.camera(W, H)
     fb = torch.zeros(W * H, dtype=torch.int32, device="cuda")
-    for counters, mrr in [("0", mr), ("1", mr)] + [("2", k) for k in range(mr + 1)]:
+    for counters, mrr in [("0", mr), ("0", 0), ("1", mr), ("2", mr)]:
         prm = device.make_params(W, H, mrr)
         os.environ["RTHIP_COUNTERS"] = counters
         ctx = device.Context(0); ctx.upload(desc)
@@ -24,5 +24,6 @@ for cfg in cfgs:
               f"nodes={s.kd_nodes_visited} tris={s.kd_tris_tested} leaves={s.kd_leaves_visited} pops={s.kd_pops}\n"
               f"   wave steps max={s.wave_steps_max} total={s.wave_steps}  wave tri-iters max={s.wave_tris_max} total={s.wave_tris}  longest wave {s.wave_cycles_max} cycles")
         print("   level rays:", list(s.level_rays[:mr + 1]))
-        print("   level ms  :", [round(x, 3) for x in s.level_ms_trace[:mr + 1]], flush=True)
+        print("   trace ms  :", [round(x, 3) for x in s.level_ms_trace[:mr + 1]])
+        print("   shade ms  :", [round(x, 3) for x in s.level_ms_shade[:mr + 1]], flush=True)
         ctx.close()
