@@ -109,9 +109,10 @@ struct __attribute__((aligned(64))) HitSlot {
 struct __attribute__((aligned(32))) ColRec {
     double r, g, b, refl;  // direct colour (later: folded colour) and the reflectance applied to the child
 };
+static const uint32_t kNoChild = 0xffffffffu;
 struct Work {
     ColRec *rec;            // [levels][N]
-    uint32_t *parent;       // [levels][N]  : index of the spawning ray in level-1
+    uint32_t *child;        // [levels][N]  : index of the reflected ray in level+1, kNoChild if none
     RayRec *rays;           // [2][N]       : ping-pong ray queues
     uint32_t *counts;       // [levels+1]   : rays per level
     unsigned long long *stats;  // [ST_COUNT]
@@ -121,7 +122,7 @@ struct Work {
     uint32_t *redo_count;       // [levels] one counter per level (zeroed with `counts`)
     uint32_t *hard;             // [N] rays of the current level that need a mesh walk (traced by the quad kernel)
     uint32_t *hard_count;       // [levels]
-    uint2 *block_stats;         // [levels][bs_stride] per workgroup of k_shade: (shadow queries, reflected rays) of the frame
+    uint2 *block_stats;         // [2][levels][bs_stride] per workgroup of k_trace_easy / k_shade: (shadow queries, reflected rays) of the frame
     uint32_t bs_stride;
     uint32_t N;
 };
@@ -572,6 +573,83 @@ __device__ __forceinline__ bool trace_stage(const SceneView &sv, V3 o, V3 d, uin
 }
 }  // namespace quad
 
+// ---------------------------------------------------------------------------- shading + spawn
+// Stage 2 of a level for ONE chunk of a workgroup (called by every thread of the workgroup): material /
+// noise / background, Lambert terms with the shadow mask (R4, R5, M*, N*, B*), and the reflected rays,
+// compacted into the next level's queue: wave ballot + prefix popcount, the four waves of a workgroup
+// combined through LDS so that ONE returning atomic per workgroup reserves the queue range.
+// `have`: this lane holds a traced ray (index i in the level, hit record h, direction d).
+struct ShadeShared {
+    uint32_t wave_cnt[kBlock / 64];
+    uint32_t block_base;
+    uint32_t part[2][kBlock / 64];
+};
+__device__ __forceinline__ void shade_and_spawn(const SceneView &sv, const FrameParams &fp, const Work &w, const uint8_t *tabs,
+                                                ShadeShared &sh, uint32_t level, bool have, uint32_t i, const HitRec &h, V3 d,
+                                                uint32_t &shadow_total, uint32_t &spawn_total) {
+    const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
+    ShadeOut so;
+    so.spawn = false;
+    so.shadow_rays = 0;
+    if (have) {
+        if (fp.renderer == RTHIP_RENDER_RAYTRACER) {
+            shade_stage(sv, tabs, h, d, level < fp.max_rec, so);
+        } else {
+            so.color = debug_shade(sv, tabs, h, d, fp.renderer - 1);
+            so.refl = 0.0;
+        }
+        ColRec cr;
+        cr.r = so.color.r; cr.g = so.color.g; cr.b = so.color.b; cr.refl = so.refl;
+        rec_at(w, level, i) = cr;
+    }
+    const unsigned long long mask = __ballot(so.spawn);
+    if (lane == 0) sh.wave_cnt[wid] = (uint32_t)__popcll(mask);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t total = sh.wave_cnt[0] + sh.wave_cnt[1] + sh.wave_cnt[2] + sh.wave_cnt[3];
+        sh.block_base = total ? atomicAdd(&w.counts[level + 1], total) : 0u;
+    }
+    __syncthreads();
+    uint32_t child = kNoChild;
+    if (so.spawn) {
+        uint32_t j = sh.block_base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+        for (uint32_t k = 0; k < wid; k++) j += sh.wave_cnt[k];
+        store_ray(w, level + 1, j, so.child_o, so.child_d, i);
+        child = j;
+        spawn_total++;
+    }
+    if (have) w.child[(size_t)level * w.N + i] = child;  // the chain k_resolve folds back to front
+    shadow_total += so.shadow_rays;
+    __syncthreads();  // wave_cnt / block_base are reused by the next chunk
+}
+// ray statistics without atomics (32 K same-address atomics cost more than the whole shading): one plain
+// read-modify-write per workgroup into its own slot (`which`: 0 = k_trace_easy, 1 = k_shade), summed on
+// the host on demand
+__device__ __forceinline__ void shade_stats_flush(const Work &w, ShadeShared &sh, uint32_t which, uint32_t level, uint32_t levels,
+                                                  uint32_t shadow_total, uint32_t spawn_total) {
+    const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
+    shadow_total = wave_sum(shadow_total);
+    spawn_total = wave_sum(spawn_total);
+    if (lane == 0) {
+        sh.part[0][wid] = shadow_total;
+        sh.part[1][wid] = spawn_total;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint2 *slot = w.block_stats + ((size_t)which * levels + level) * w.bs_stride + blockIdx.x;
+        uint2 v = *slot;
+        v.x += sh.part[0][0] + sh.part[0][1] + sh.part[0][2] + sh.part[0][3];
+        v.y += sh.part[1][0] + sh.part[1][1] + sh.part[1][2] + sh.part[1][3];
+        *slot = v;
+    }
+}
+__device__ __forceinline__ void stage_perlin_tables(const SceneView &sv, uint32_t n_tables) {
+    const uint32_t words = n_tables * 64;
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(sv.perlin_tables);
+    for (uint32_t k = threadIdx.x; k < words; k += kBlock) lds_dyn[k] = src[k];
+    __syncthreads();
+}
+
 // ---------------------------------------------------------------------------- easy rays
 // Stage 1a of a level for the BVH path (accel = 0), one ray per lane: every query of the ray over the
 // analytic shapes, and for each mesh only a conservative test of the ray against the four root boxes
@@ -678,12 +756,20 @@ __device__ __forceinline__ bool trace_stage(const SceneView &sv, V3 o, V3 d, uin
 }
 }  // namespace easy
 
+// Also stage 2 for the rays it finishes: they are shaded on the spot (no hit record leaves the
+// registers) and their reflected rays go straight to the next level's queue.
 template <bool COUNT>
-__global__ __launch_bounds__(kBlock, RT_TRACE_OCC) void k_trace_easy(SceneView sv, FrameParams fp, Work w, uint32_t level) {
+__global__ __launch_bounds__(kBlock, RT_TRACE_OCC) void k_trace_easy(SceneView sv, FrameParams fp, Work w, uint32_t level,
+                                                                      uint32_t n_tables, uint32_t levels) {
+    __shared__ ShadeShared sh;
     const uint32_t n = (level == 0) ? fp.N0 : w.counts[level];
+    if (blockIdx.x * kBlock >= n) return;
+    const uint8_t *tabs = reinterpret_cast<const uint8_t *>(lds_dyn);
+    stage_perlin_tables(sv, n_tables);
     const uint32_t n_shadow = fp.renderer == RTHIP_RENDER_RAYTRACER ? sv.n_lights : 0u;  // DebugRaycaster: closest hit only
     const uint32_t lane = threadIdx.x & 63u;
     KdCounters kc = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t shadow_total = 0, spawn_total = 0;
     const long long t_start = COUNT ? clock64() : 0;
     for (uint32_t base = blockIdx.x * kBlock; base < n; base += gridDim.x * kBlock) {
         const uint32_t j = base + threadIdx.x;
@@ -695,10 +781,7 @@ __global__ __launch_bounds__(kBlock, RT_TRACE_OCC) void k_trace_easy(SceneView s
             uint32_t s = i / fp.n_pix_slots;  // SSAA sub-sample (0 when aa is off)
             pix_slot = i - s * fp.n_pix_slots;
             uint32_t x = 0, y = 0;
-            if (live && !slot_to_pixel(fp, pix_slot, x, y)) {
-                store_no_ray(w, i);  // slot outside the image
-                live = false;
-            }
+            if (live && !slot_to_pixel(fp, pix_slot, x, y)) live = false;  // slot outside the image: k_resolve skips it too
             double fx = (double)x, fy = (double)y;
             if (fp.aa) {  // Raytracer.cpp:134-138: dx outer, dy inner, offsets +-0.5
                 int dx = (int)(s / 3) - 1, dy = (int)(s % 3) - 1;
@@ -706,9 +789,6 @@ __global__ __launch_bounds__(kBlock, RT_TRACE_OCC) void k_trace_easy(SceneView s
                 fy = (double)((float)(int)y + (float)dy * .5f);
             }
             screen_ray(fp.cam, fp.W, fp.H, fx, fy, o, d);
-            if (live) {
-                store_ray(w, 0, i, o, d, 0u);  // the shade stage needs the direction (background, reflection)
-            }
         } else if (live) {
             const RayRec r = ray_at(w, level, i);
             o = mk(r.ox, r.oy, r.oz);
@@ -716,22 +796,25 @@ __global__ __launch_bounds__(kBlock, RT_TRACE_OCC) void k_trace_easy(SceneView s
         }
         HitRec h;
         const bool done = easy::trace_stage<COUNT>(sv, o, d, n_shadow, live, h, kc);
-        // hard rays -> list (one atomic per wave)
+        // hard rays -> list (one atomic per wave); the quad kernel traces them, k_shade shades them
         const bool is_hard = live && !done;
         const unsigned long long mask = __ballot(is_hard);
         if (mask) {
             uint32_t wave_base = 0;
             if (lane == (uint32_t)(__ffsll((long long)mask) - 1)) wave_base = atomicAdd(&w.hard_count[0], (uint32_t)__popcll(mask));
             wave_base = __shfl(wave_base, __ffsll((long long)mask) - 1, 64);
-            if (is_hard) w.hard[wave_base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = i;
+            if (is_hard) {
+                w.hard[wave_base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = i;
+                if (level == 0) store_ray(w, 0, i, o, d, 0u);  // k_shade needs the direction (background, reflection)
+            }
         }
-        if (!live || !done) continue;
-        store_hit(w, i, h);
-        if (level == 0 && w.id_shape && i / fp.n_pix_slots == (fp.aa ? 4u : 0u)) {
+        if (live && done && level == 0 && w.id_shape && i / fp.n_pix_slots == (fp.aa ? 4u : 0u)) {
             w.id_shape[pix_slot] = h.shape;
             w.id_tri[pix_slot] = -1;
         }
+        shade_and_spawn(sv, fp, w, tabs, sh, level, live && done, i, h, d, shadow_total, spawn_total);
     }
+    shade_stats_flush(w, sh, 0, level, levels, shadow_total, spawn_total);
     if (COUNT) trace_counters_flush(fp, w, kc, 0, t_start);
 }
 
@@ -790,105 +873,70 @@ __global__ __launch_bounds__(kBlock, RT_QUAD_OCC) void k_trace_quad(SceneView sv
     if (COUNT) trace_counters_flush(fp, w, kc, max_ray_nodes, t_start);
 }
 
-// Stage 2 of a level: material / noise / background, Lambert terms with the shadow mask, and the
-// reflected rays, compacted into the next level's queue: wave ballot + prefix popcount, the four
-// waves of a workgroup combined through LDS so that ONE returning atomic per workgroup reserves the
-// queue range (32 K per-wave atomics on one word cost more than the shading itself).
-// The Perlin tables (256 B each) are staged in LDS: their chained lookups are the latency chain of
-// every sky / marble sample.
-__global__ __launch_bounds__(kBlock, RT_SHADE_OCC) void k_shade(SceneView sv, FrameParams fp, Work w, uint32_t level, uint32_t n_tables) {
-    uint8_t *tabs = reinterpret_cast<uint8_t *>(lds_dyn);
-    __shared__ uint32_t wave_cnt[kBlock / 64];
-    __shared__ uint32_t block_base;
-    {
-        const uint32_t words = n_tables * 64;
-        const uint32_t *src = reinterpret_cast<const uint32_t *>(sv.perlin_tables);
-        for (uint32_t k = threadIdx.x; k < words; k += kBlock) lds_dyn[k] = src[k];
-        __syncthreads();
-    }
-    const uint32_t n = (level == 0) ? fp.N0 : w.counts[level];
-    const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
+// Stage 2 of a level for the rays that went through a hit record: LIST = true, the hard rays of the BVH
+// path (traced by k_trace_quad / the redo kernel); LIST = false, every ray of the level (accel = 1, where
+// k_trace does all the tracing).  The Perlin tables (256 B each) are staged in LDS: their chained lookups
+// are the latency chain of every sky / marble sample.
+template <bool LIST>
+__global__ __launch_bounds__(kBlock, RT_SHADE_OCC) void k_shade(SceneView sv, FrameParams fp, Work w, uint32_t level, uint32_t n_tables,
+                                                                 uint32_t levels) {
+    __shared__ ShadeShared sh;
+    const uint32_t n = LIST ? w.hard_count[0] : ((level == 0) ? fp.N0 : w.counts[level]);
+    if (blockIdx.x * kBlock >= n) return;
+    const uint8_t *tabs = reinterpret_cast<const uint8_t *>(lds_dyn);
+    stage_perlin_tables(sv, n_tables);
     uint32_t shadow_total = 0, spawn_total = 0;
     for (uint32_t base = blockIdx.x * kBlock; base < n; base += gridDim.x * kBlock) {
-        uint32_t i = base + threadIdx.x;
-        ShadeOut so;
-        so.spawn = false;
-        so.shadow_rays = 0;
+        const uint32_t j = base + threadIdx.x;
+        uint32_t i = 0;
         HitSlot hs;
         hs.shape = -2;
-        if (i < n) hs = w.hit[i];
-        const int32_t shape = hs.shape;
-        if (shape > -2) {
-            HitRec h;
-            h.shape = shape;
-            h.tri = -1;
-            h.shadow_mask = hs.mask;
-            h.local = mk(hs.lx, hs.ly, hs.lz);
-            h.normal = mk(hs.nx, hs.ny, hs.nz);
+        if (j < n) {
+            i = LIST ? w.hard[j] : j;
+            hs = w.hit[i];
+        }
+        HitRec h;
+        h.shape = hs.shape;
+        h.tri = -1;
+        h.shadow_mask = hs.mask;
+        h.local = mk(hs.lx, hs.ly, hs.lz);
+        h.normal = mk(hs.nx, hs.ny, hs.nz);
+        V3 d = mk(0, 0, 1);
+        if (hs.shape > -2) {
             const RayRec rr = ray_at(w, level, i);
-            V3 d = mk(rr.dx, rr.dy, rr.dz);
-            if (fp.renderer == RTHIP_RENDER_RAYTRACER) {
-                shade_stage(sv, tabs, h, d, level < fp.max_rec, so);
-            } else {
-                so.color = debug_shade(sv, tabs, h, d, fp.renderer - 1);
-                so.refl = 0.0;
-            }
-            ColRec cr;
-            cr.r = so.color.r; cr.g = so.color.g; cr.b = so.color.b; cr.refl = so.refl;
-            rec_at(w, level, i) = cr;
-            if (level > 0) w.parent[(size_t)level * w.N + i] = rr.parent;  // for k_fold; full-line store (all lanes, in order)
+            d = mk(rr.dx, rr.dy, rr.dz);
         }
-        // compaction of the reflected rays
-        unsigned long long mask = __ballot(so.spawn);
-        if (lane == 0) wave_cnt[wid] = (uint32_t)__popcll(mask);
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            uint32_t total = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
-            block_base = total ? atomicAdd(&w.counts[level + 1], total) : 0u;
-        }
-        __syncthreads();
-        if (so.spawn) {
-            uint32_t j = block_base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-            for (uint32_t k = 0; k < wid; k++) j += wave_cnt[k];
-            store_ray(w, level + 1, j, so.child_o, so.child_d, i);
-            spawn_total++;
-        }
-        shadow_total += so.shadow_rays;
-        __syncthreads();  // wave_cnt / block_base are reused by the next chunk
+        shade_and_spawn(sv, fp, w, tabs, sh, level, hs.shape > -2, i, h, d, shadow_total, spawn_total);
     }
-    // ray statistics without atomics (32 K same-address atomics cost more than the whole shading):
-    // one plain read-modify-write per workgroup into its own slot, summed on the host on demand
-    shadow_total = wave_sum(shadow_total);
-    spawn_total = wave_sum(spawn_total);
-    __shared__ uint32_t part[2][kBlock / 64];
-    if (lane == 0) {
-        part[0][wid] = shadow_total;
-        part[1][wid] = spawn_total;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint2 *slot = w.block_stats + (size_t)level * w.bs_stride + blockIdx.x;
-        uint2 v = *slot;
-        v.x += part[0][0] + part[0][1] + part[0][2] + part[0][3];
-        v.y += part[1][0] + part[1][1] + part[1][2] + part[1][3];
-        *slot = v;
-    }
+    shade_stats_flush(w, sh, 1, level, levels, shadow_total, spawn_total);
 }
 
-// level k -> k-1:  parent.colour = directLighting (+) (child (x) reflectance)   (Raytracer.cpp:283-286)
-__global__ __launch_bounds__(kBlock) void k_fold(Work w, uint32_t level) {
-    const uint32_t n = w.counts[level];
-    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
-        uint32_t p = w.parent[(size_t)level * w.N + i];
-        const ColRec ch = rec_at(w, level, i);
-        ColRec pr = rec_at(w, level - 1, p);
-        Col c = fold(Col{pr.r, pr.g, pr.b}, Col{ch.r, ch.g, ch.b}, pr.refl);
-        pr.r = c.r; pr.g = c.g; pr.b = c.b;
-        rec_at(w, level - 1, p) = pr;
+// One pixel sample: its chain of rays (level 0 -> reflected ray -> ...) folded back to front,
+// C_k = directLighting_k (+) C_{k+1} (x) reflectance_k with the reference's clamping Color algebra
+// (Raytracer.cpp:283-286; the clamps forbid a forward throughput product).  Every ray has at most one
+// reflected ray, so the chain is a list: no per-level fold kernels, no global synchronisation.
+__device__ __forceinline__ Col resolve_chain(const Work &w, uint32_t i0, uint32_t max_level) {
+    uint32_t idx[RTHIP_MAX_RECURSION + 1];
+    uint32_t level = 0, i = i0;
+    for (;;) {
+        idx[level] = i;
+        if (level == max_level) break;
+        const uint32_t c = w.child[(size_t)level * w.N + i];
+        if (c == kNoChild) break;
+        i = c;
+        level++;
     }
+    const ColRec q = rec_at(w, level, i);
+    Col c = Col{q.r, q.g, q.b};
+    while (level > 0) {
+        level--;
+        const ColRec pr = rec_at(w, level, idx[level]);
+        c = fold(Col{pr.r, pr.g, pr.b}, c, pr.refl);
+    }
+    return c;
 }
 
-// level-0 colours -> pixels (Common.cpp:275-282); SSAA: result += c * (1.0f/9.0f), clamped (Raytracer.cpp:139)
+// chains -> pixels (Common.cpp:275-282); SSAA: result += c * (1.0f/9.0f), clamped (Raytracer.cpp:139)
 __global__ __launch_bounds__(kBlock) void k_resolve(FrameParams fp, Work w, uint32_t *pixels, int32_t *out_shape,
                                                     int32_t *out_tri) {
     uint32_t ps = blockIdx.x * kBlock + threadIdx.x;
@@ -900,14 +948,11 @@ __global__ __launch_bounds__(kBlock) void k_resolve(FrameParams fp, Work w, uint
         c = Col{0, 0, 0};
         const double k = (double)(1.0f / 9.0f);
         for (uint32_t s = 0; s < 9; s++) {
-            size_t i = (size_t)s * fp.n_pix_slots + ps;
-            const ColRec q = rec_at(w, 0, (uint32_t)i);
-            Col r = Col{q.r, q.g, q.b};
+            Col r = resolve_chain(w, s * fp.n_pix_slots + ps, fp.max_rec);
             c = c_add(c, c_scale(r, k));
         }
     } else {
-        const ColRec q = rec_at(w, 0, ps);
-        c = Col{q.r, q.g, q.b};
+        c = resolve_chain(w, ps, fp.max_rec);
     }
     size_t idx = fp.layout ? (size_t)fp.q0 * fp.tile_w * fp.tile_h + ps : (size_t)y * fp.W + x;
     pixels[idx] = c_pack(c);
@@ -1004,7 +1049,7 @@ struct rthip_ctx {
     bool has_scene = false;
     uint32_t stack_cap = 1;
     // frame workspace
-    DevBuf rec, parent, rays, counts, stats, block_stats, ids, pixels_tmp, ids_out, hits, redo, probe[8];
+    DevBuf rec, child, rays, counts, stats, block_stats, ids, pixels_tmp, ids_out, hits, redo, probe[8];
     uint32_t bs_stride = 0, bs_levels = 0;
     uint32_t n_tables = 0;
     bool has_meshes = false;
@@ -1056,7 +1101,7 @@ int rthip_destroy(rthip_ctx *c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     DevBuf *all[] = {&c->shapes, &c->meshes, &c->kd_nodes, &c->kd_bounds, &c->kd_refs, &c->tris, &c->tri_normals,
-                     &c->materials, &c->noises, &c->perlin, &c->worley, &c->lights, &c->rec, &c->parent, &c->rays,
+                     &c->materials, &c->noises, &c->perlin, &c->worley, &c->lights, &c->rec, &c->child, &c->rays,
                      &c->counts, &c->stats, &c->ids, &c->pixels_tmp, &c->ids_out, &c->bvh_nodes, &c->bvh_tris, &c->bvh_index, &c->kd_planes, &c->hits, &c->redo, &c->block_stats};
     for (DevBuf *b : all) b->release();
     for (DevBuf &b : c->probe) b.release();
@@ -1309,19 +1354,19 @@ static int render_frame(rthip_ctx *c, const rthip_camera *cam, const rthip_param
     const size_t N = (size_t)tiles_per_chunk * per_tile * spp;
 
     if (c->rec.ensure(sizeof(ColRec) * N * levels)) return RTHIP_E_HIP;
-    if (c->parent.ensure(sizeof(uint32_t) * N * levels)) return RTHIP_E_HIP;
+    if (c->child.ensure(sizeof(uint32_t) * N * levels)) return RTHIP_E_HIP;
     if (c->rays.ensure(sizeof(RayRec) * 2 * N)) return RTHIP_E_HIP;
     if (c->counts.ensure(sizeof(uint32_t) * 3 * (RTHIP_MAX_RECURSION + 3))) return RTHIP_E_HIP;
     if (c->stats.ensure(sizeof(unsigned long long) * ST_COUNT)) return RTHIP_E_HIP;
     c->bs_stride = (uint32_t)((N + kBlock - 1) / kBlock);
     c->bs_levels = levels;
-    if (c->block_stats.ensure(sizeof(uint2) * (size_t)c->bs_stride * levels)) return RTHIP_E_HIP;
+    if (c->block_stats.ensure(sizeof(uint2) * 2 * (size_t)c->bs_stride * levels)) return RTHIP_E_HIP;
     if (c->ids.ensure(sizeof(int32_t) * 2 * (size_t)tiles_per_chunk * per_tile)) return RTHIP_E_HIP;
     if (c->hits.ensure(sizeof(HitSlot) * N)) return RTHIP_E_HIP;
     if (c->redo.ensure(sizeof(uint32_t) * 2 * N)) return RTHIP_E_HIP;
     Work w;
     w.rec = (ColRec *)c->rec.p;
-    w.parent = (uint32_t *)c->parent.p;
+    w.child = (uint32_t *)c->child.p;
     w.rays = (RayRec *)c->rays.p;
     w.counts = (uint32_t *)c->counts.p;
     w.stats = (unsigned long long *)c->stats.p;
@@ -1349,7 +1394,7 @@ static int render_frame(rthip_ctx *c, const rthip_camera *cam, const rthip_param
     const size_t lds_tables = (size_t)c->n_tables * 256;
 
     HIP_TRY(hipMemsetAsync(w.stats, 0, sizeof(unsigned long long) * ST_COUNT, c->stream));
-    HIP_TRY(hipMemsetAsync(w.block_stats, 0, sizeof(uint2) * (size_t)c->bs_stride * levels, c->stream));
+    HIP_TRY(hipMemsetAsync(w.block_stats, 0, sizeof(uint2) * 2 * (size_t)c->bs_stride * levels, c->stream));
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
     size_t ev_used = 0;
     auto get_event = [&](hipEvent_t *e) -> int {
@@ -1382,9 +1427,9 @@ static int render_frame(rthip_ctx *c, const rthip_camera *cam, const rthip_param
             w.hard_count = w.counts + 2 * (RTHIP_MAX_RECURSION + 3) + level;
             if (p->accel == 0) {
                 if (c->count_kd)
-                    hipLaunchKernelGGL((k_trace_easy<true>), dim3(grid), dim3(kBlock), 0, c->stream, c->sv, fp, w, level);
+                    hipLaunchKernelGGL((k_trace_easy<true>), dim3(grid), dim3(kBlock), lds_tables, c->stream, c->sv, fp, w, level, c->n_tables, levels);
                 else
-                    hipLaunchKernelGGL((k_trace_easy<false>), dim3(grid), dim3(kBlock), 0, c->stream, c->sv, fp, w, level);
+                    hipLaunchKernelGGL((k_trace_easy<false>), dim3(grid), dim3(kBlock), lds_tables, c->stream, c->sv, fp, w, level, c->n_tables, levels);
                 if (c->has_meshes) {  // the rays that need a mesh walk (count on the device: the grid is an upper bound, strided)
                     uint32_t qgrid = (fp.N0 + quad::kRaysPerBlock - 1) / quad::kRaysPerBlock;
                     if (qgrid > kMaxGridQuad) qgrid = kMaxGridQuad;
@@ -1407,13 +1452,13 @@ static int render_frame(rthip_ctx *c, const rthip_camera *cam, const rthip_param
                     hipLaunchKernelGGL((k_trace<false, false, false>), dim3(grid), dim3(kBlock), lds_bytes, c->stream, c->sv, fp, w, level, c->stack_cap);
                 if (c->profile_launches) HIP_TRY(hipEventRecord(eb, c->stream));
             }
-            hipLaunchKernelGGL(k_shade, dim3(grid), dim3(kBlock), lds_tables, c->stream, c->sv, fp, w, level, c->n_tables);
+            if (p->accel == 0) {
+                if (c->has_meshes)
+                    hipLaunchKernelGGL((k_shade<true>), dim3(grid), dim3(kBlock), lds_tables, c->stream, c->sv, fp, w, level, c->n_tables, levels);
+            } else {
+                hipLaunchKernelGGL((k_shade<false>), dim3(grid), dim3(kBlock), lds_tables, c->stream, c->sv, fp, w, level, c->n_tables, levels);
+            }
             if (c->profile_launches) HIP_TRY(hipEventRecord(ec, c->stream));
-        }
-        for (uint32_t level = levels - 1; level >= 1; level--) {
-            uint32_t grid = (fp.N0 + kBlock - 1) / kBlock;
-            if (grid > kMaxGridLevel) grid = kMaxGridLevel;
-            hipLaunchKernelGGL(k_fold, dim3(grid), dim3(kBlock), 0, c->stream, w, level);
         }
         hipLaunchKernelGGL(k_resolve, dim3((fp.n_pix_slots + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, fp, w,
                            d_pixels, d_shape, d_tri);
@@ -1453,7 +1498,7 @@ static int finish_stats(rthip_ctx *c, const rthip_params *p) {
     c->last.pixels = px;
     c->last.rays_primary = px * (p->aa_mode ? 9 : 1);
     {
-        std::vector<uint2> parts((size_t)c->bs_stride * c->bs_levels);
+        std::vector<uint2> parts(2 * (size_t)c->bs_stride * c->bs_levels);
         if (!parts.empty()) HIP_TRY(hipMemcpy(parts.data(), c->block_stats.p, sizeof(uint2) * parts.size(), hipMemcpyDeviceToHost));
         uint64_t shadow = 0, reflect = 0;
         for (const uint2 &v : parts) { shadow += v.x; reflect += v.y; }
