@@ -243,6 +243,7 @@ typedef struct {
      * the grid-stride iterations of that wave), and the totals */
     uint64_t wave_steps_max, wave_tris_max, wave_steps, wave_tris;
     uint64_t wave_cycles_max;    /* longest-lived trace wave of the frame, shader clock cycles */
+    uint64_t fetch_cycles;       /* cycles waves waited for BVH node fetches (RTHIP_COUNTERS=2: of the longest wave) */
     /* per recursion level of the last chunk: rays in the level's queue, and (RTHIP_PROFILE_LAUNCHES=1)
      * the duration of the level's trace kernels and of its shade kernel */
     uint32_t level_rays[RTHIP_MAX_RECURSION + 1];

@@ -131,6 +131,7 @@ RT_HD KdStack make_stack(uint32_t *base, uint32_t stride, uint32_t cap, float *t
 struct KdCounters {
     uint32_t nodes, leaves, tris, pops, shapes, mesh_hits;
     uint32_t wave_steps, wave_tris;  // loop iterations the WAVE executed (one lane counts each): divergence diagnostic
+    uint32_t fetch_cycles;           // cycles the wave waited for BVH node fetches (one lane counts)
 };
 #if defined(__HIP_DEVICE_COMPILE__)
 __device__ __forceinline__ uint32_t rt_first_active() {

@@ -78,7 +78,7 @@ static const uint32_t kBlock = 256;           // 4 waves per workgroup
 #endif
 static const uint32_t kMaxGridQuad = 16384;    // same for the quad kernel (64 rays per workgroup)
 static const uint32_t kMaxGridLevel = 4096;   // queue levels: grid-stride over a bounded grid
-enum { ST_KD_NODES = 0, ST_KD_TRIS, ST_KD_LEAVES, ST_KD_POPS, ST_SHAPES, ST_MESH_HITS, ST_KD_MAXRAY, ST_WAVE_STEPS_MAX, ST_WAVE_TRIS_MAX, ST_WAVE_STEPS, ST_WAVE_TRIS, ST_WAVE_CYCLES_MAX, ST_COUNT };
+enum { ST_KD_NODES = 0, ST_KD_TRIS, ST_KD_LEAVES, ST_KD_POPS, ST_SHAPES, ST_MESH_HITS, ST_KD_MAXRAY, ST_WAVE_STEPS_MAX, ST_WAVE_TRIS_MAX, ST_WAVE_STEPS, ST_WAVE_TRIS, ST_WAVE_CYCLES_MAX, ST_FETCH_CYCLES, ST_COUNT };
 
 // Per-frame constants
 struct FrameParams {
@@ -190,6 +190,7 @@ __device__ __forceinline__ void trace_counters_flush(const FrameParams &fp, cons
         kc.mesh_hits = wave_sum(kc.mesh_hits);
         kc.wave_steps = wave_sum(kc.wave_steps);
         kc.wave_tris = wave_sum(kc.wave_tris);
+        kc.fetch_cycles = wave_sum(kc.fetch_cycles);
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
             uint32_t o2 = __shfl_xor(max_ray_nodes, off, 64);
@@ -201,6 +202,8 @@ __device__ __forceinline__ void trace_counters_flush(const FrameParams &fp, cons
                 w.stats[ST_WAVE_STEPS_MAX] = kc.wave_steps;  // racy by design: diagnostics of "a" longest wave
                 w.stats[ST_WAVE_TRIS_MAX] = kc.wave_tris;
                 w.stats[ST_KD_MAXRAY] = max_ray_nodes;
+                w.stats[ST_FETCH_CYCLES] = kc.fetch_cycles;
+                w.stats[ST_WAVE_STEPS] = kc.wave_steps;
             }
         } else if (lane == 0 && (kc.nodes | kc.shapes)) {
             atomicMax(&w.stats[ST_KD_MAXRAY], (unsigned long long)max_ray_nodes);
@@ -209,6 +212,7 @@ __device__ __forceinline__ void trace_counters_flush(const FrameParams &fp, cons
             atomicMax(&w.stats[ST_WAVE_TRIS_MAX], (unsigned long long)kc.wave_tris);
             atomicAdd(&w.stats[ST_WAVE_STEPS], (unsigned long long)kc.wave_steps);
             atomicAdd(&w.stats[ST_WAVE_TRIS], (unsigned long long)kc.wave_tris);
+            atomicAdd(&w.stats[ST_FETCH_CYCLES], (unsigned long long)kc.fetch_cycles);
             atomicAdd(&w.stats[ST_KD_NODES], (unsigned long long)kc.nodes);
             atomicAdd(&w.stats[ST_KD_TRIS], (unsigned long long)kc.tris);
             atomicAdd(&w.stats[ST_KD_LEAVES], (unsigned long long)kc.leaves);
@@ -232,7 +236,7 @@ __global__ __launch_bounds__(kBlock, RT_TRACE_OCC) void k_trace(SceneView sv, Fr
                             FAST ? reinterpret_cast<float *>(lds_dyn + (size_t)stack_cap * kBlock) + threadIdx.x : nullptr);
     const uint32_t n = REDO ? w.redo_count[0] : ((level == 0) ? fp.N0 : w.counts[level]);
     const uint32_t n_shadow = fp.renderer == RTHIP_RENDER_RAYTRACER ? sv.n_lights : 0u;  // DebugRaycaster: closest hit only
-    KdCounters kc = {0, 0, 0, 0, 0, 0, 0, 0};
+    KdCounters kc = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t max_ray_nodes = 0;
     const long long t_start = COUNT ? clock64() : 0;
     for (uint32_t base = blockIdx.x * kBlock; base < n; base += gridDim.x * kBlock) {
@@ -302,7 +306,6 @@ __global__ __launch_bounds__(kBlock, RT_TRACE_OCC) void k_trace(SceneView sv, Fr
 // operation is quad-uniform by construction (ray state is replicated bit-identically in the 4 lanes).
 namespace quad {
 constexpr int kXor1 = 0xB1, kXor2 = 0x4E, kRot1 = 0x39, kRot3 = 0x93;  // quad_perm [1,0,3,2] [2,3,0,1] [1,2,3,0] [3,0,1,2]
-static const uint32_t kCap = 24, kStride = 25;  // stack entries per quad; odd stride spreads the LDS banks
 static const uint32_t kRaysPerBlock = kBlock / 4;
 
 template <int CTRL> __device__ __forceinline__ uint32_t dpp(uint32_t v) {
@@ -313,9 +316,12 @@ template <int CTRL> __device__ __forceinline__ double dpp(double v) {
     uint32_t lo = dpp<CTRL>((uint32_t)b), hi = dpp<CTRL>((uint32_t)(b >> 32));
     return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
+// The quad's stack of pending children in LDS: 8-byte entries {child word, entry parameter}, sized by the
+// tree (3 * depth + 1 entries can never overflow: a step pushes at most three children and descends one
+// level), plus one dummy entry that absorbs the writes of lanes with nothing to push.
 struct Stack {
-    uint32_t *w;
-    float *t;
+    uint2 *e;
+    uint32_t cap;  // usable entries; e[cap] is the dummy
 };
 
 // lexicographic min of (d, id) over the quad; id = 0xffffffff means "nothing"
@@ -352,9 +358,17 @@ __device__ __forceinline__ bool tri_eval(const rthip_tri &t, V3 o, V3 d, double 
     return true;
 }
 
+template <int CTRL> __device__ __forceinline__ uint32_t min_dpp(uint32_t v) {
+    const uint32_t o = dpp<CTRL>(v);
+    return o < v ? o : v;
+}
+// The interior loop is written branch-free (selects, a dummy stack slot, a speculative read of the stack
+// top): with 16 quads in different phases every branch of a step would be taken by some quad anyway, and
+// a lone wave pays ~20 cycles per taken branch.  A quad whose popped entry is culled carries kSkip for
+// one step (its box tests are forced to miss and it pops again).
 template <bool COUNT>
 __device__ __forceinline__ void mesh_closest(const SceneView &sv, const rthip_mesh &m, V3 o, V3 d, Stack qs, uint32_t q,
-                                             float t_stop, TriBest &best, bool &overflow, KdCounters &cnt) {
+                                             float t_stop, TriBest &best, KdCounters &cnt) {
     best.hit = false;
     best.d = DBL_MAX;
     best.tri = 0xffffffffu;
@@ -364,27 +378,27 @@ __device__ __forceinline__ void mesh_closest(const SceneView &sv, const rthip_me
     const rthip_tri *tris = sv.bvh_tris + m.bvh_tri_base;
     const uint32_t *index = sv.bvh_tri_index + m.bvh_tri_base;
     const BvhRay r = bvh_ray(o, d, m.abs_max);
+    const uint32_t kSkip = 0x7ffffffeu;              // "pop again": no leaf bit, never a node index
+    const uint32_t kDone = RTHIP_BVH_ABSENT;         // has the leaf bit: leaves the interior loop
+    const uint32_t kNone = 0xfffffffcu;
+    const uint32_t qbit = 1u << q, below = qbit - 1u;
     float tmax = 3.0e38f;
     uint32_t n = 0;
     uint32_t cur = 0;
-    auto pop = [&]() {
-        uint32_t c = RTHIP_BVH_ABSENT;
-        while (n) {
-            n--;
-            const float t = qs.t[n];
-            const uint32_t cw = qs.w[n];
-            if (COUNT) cnt.pops += (q == 0);
-            if (t <= tmax) { c = cw; break; }
-        }
-        return c;
-    };
     for (;;) {
-        while (!(cur & RTHIP_BVH_LEAF)) {  // RTHIP_BVH_ABSENT (= done) has the leaf bit set
-            const uint4 *p = reinterpret_cast<const uint4 *>(nodes + ((size_t)cur << 7));
+        while (!(cur & RTHIP_BVH_LEAF)) {
+            const bool valid = cur != kSkip;
+            const uint2 top = qs.e[(n ? n : 1u) - 1u];  // speculative: only used when no child is hit
+            const uint4 *p = reinterpret_cast<const uint4 *>(nodes + ((size_t)(valid ? cur : 0u) << 7));
+            const long long tm0 = COUNT ? clock64() : 0;
             const uint4 A = p[0], B = p[1];  // lo.xyz hi.x | hi.yz child pad
             if (COUNT) {
-                cnt.nodes += (q == 0);
-                cnt.wave_steps += rt_first_active();
+                asm volatile("" ::"v"(A.x), "v"(B.x));  // the loads have landed
+                const uint32_t first = rt_first_active();
+                cnt.fetch_cycles += first ? (uint32_t)(clock64() - tm0) : 0u;
+                cnt.nodes += (q == 0 && valid);
+                cnt.pops += (q == 0 && !valid);
+                cnt.wave_steps += first;
             }
             const float lo[3] = {__uint_as_float(A.x), __uint_as_float(A.y), __uint_as_float(A.z)};
             const float hi[3] = {__uint_as_float(A.w), __uint_as_float(B.x), __uint_as_float(B.y)};
@@ -392,30 +406,29 @@ __device__ __forceinline__ void mesh_closest(const SceneView &sv, const rthip_me
             float tn;
             bool h;
             bvh_slab(lo, hi, r, tmax, tn, h);
-            h = h && child != RTHIP_BVH_ABSENT;
-            const uint32_t kNone = 0xfffffffcu;
+            h = h && valid && child != RTHIP_BVH_ABSENT;
             const uint32_t key = h ? ((__float_as_uint(tn) & ~3u) | q) : (kNone | q);  // tn >= 0: bit order == value order
-            const uint32_t k1 = dpp<kRot1>(key), k2 = dpp<kXor2>(key), k3 = dpp<kRot3>(key);
-            const uint32_t rank = (uint32_t)(k1 < key) + (uint32_t)(k2 < key) + (uint32_t)(k3 < key);
-            const uint32_t nhit = (uint32_t)h + (uint32_t)(k1 < kNone) + (uint32_t)(k2 < kNone) + (uint32_t)(k3 < kNone);
-            uint32_t sel = (h && rank == 0) ? child : 0u;  // node indices are >= 1 below the root, leaf words have bit 31
+            uint32_t kmin = min_dpp<kXor1>(key);
+            kmin = min_dpp<kXor2>(kmin);
+            uint32_t hm = h ? qbit : 0u;  // which lanes of the quad hit
+            hm |= dpp<kXor1>(hm);
+            hm |= dpp<kXor2>(hm);
+            const bool nearest = key == kmin;
+            uint32_t sel = (h && nearest) ? child : 0u;  // node indices are >= 1 below the root, leaf words have bit 31
             sel |= dpp<kXor1>(sel);
             sel |= dpp<kXor2>(sel);
-            if (nhit > 1) {
-                if (n + nhit - 1 > kCap) {  // rare: the redo kernel walks this ray with a full-depth stack
-                    overflow = true;
-                    return;
-                }
-                if (h && rank) {
-                    const uint32_t slot = n + nhit - 1 - rank;  // nearest of the rest on top
-                    qs.w[slot] = child;
-                    qs.t[slot] = tn;
-                }
-                n += nhit - 1;
-            }
-            cur = nhit ? sel : pop();
+            // the other hit children go to the stack (lane order); lanes with nothing to push write the dummy
+            const uint32_t others = hm & ~(1u << (kmin & 3u));
+            const bool push = h && !nearest;
+            const uint32_t slot = push ? n + (uint32_t)__popc(others & below) : qs.cap;
+            qs.e[slot] = make_uint2(child, __float_as_uint(tn));
+            const uint32_t nh = (uint32_t)__popc(hm);
+            const bool popped_ok = __uint_as_float(top.y) <= tmax;
+            const uint32_t after_pop = n ? (popped_ok ? top.x : kSkip) : kDone;
+            cur = nh ? sel : after_pop;
+            n = nh ? n + nh - 1u : (n ? n - 1u : 0u);
         }
-        if (cur == RTHIP_BVH_ABSENT) break;
+        if (cur == kDone) break;
         {   // leaf: one triangle per lane
             const uint32_t first = cur & RTHIP_BVH_FIRST_MASK, count = ((cur >> RTHIP_BVH_COUNT_SHIFT) & 7u) + 1u;
             if (COUNT) {
@@ -442,7 +455,12 @@ __device__ __forceinline__ void mesh_closest(const SceneView &sv, const rthip_me
                 tmax = fminf(bvh_tmax_of(dd), t_stop);
             }
         }
-        cur = pop();
+        {   // next pending child (a culled one is dropped by the interior loop)
+            const uint2 top = qs.e[(n ? n : 1u) - 1u];
+            const bool popped_ok = __uint_as_float(top.y) <= tmax;
+            cur = n ? (popped_ok ? top.x : kSkip) : kDone;
+            n = n ? n - 1u : 0u;
+        }
     }
 }
 
@@ -507,12 +525,7 @@ __device__ __forceinline__ int32_t cast_ray(const SceneView &sv, V3 o, V3 d, Sta
         }
         const float t_stop = any_hit ? anyhit_t_stop(fwd, sh->rt_lin, sh->rt_t, o, ld) : 3.0e38f;
         TriBest tb;
-        bool overflow = false;
-        mesh_closest<COUNT>(sv, m, lo, ld, qs, q, t_stop, tb, overflow, cnt);
-        if (overflow) {
-            redo = true;
-            continue;
-        }
+        mesh_closest<COUNT>(sv, m, lo, ld, qs, q, t_stop, tb, cnt);
         if (!tb.hit) continue;
         V3 p;
         double u, v, w;
@@ -768,7 +781,7 @@ __global__ __launch_bounds__(kBlock, RT_TRACE_OCC) void k_trace_easy(SceneView s
     stage_perlin_tables(sv, n_tables);
     const uint32_t n_shadow = fp.renderer == RTHIP_RENDER_RAYTRACER ? sv.n_lights : 0u;  // DebugRaycaster: closest hit only
     const uint32_t lane = threadIdx.x & 63u;
-    KdCounters kc = {0, 0, 0, 0, 0, 0, 0, 0};
+    KdCounters kc = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t shadow_total = 0, spawn_total = 0;
     const long long t_start = COUNT ? clock64() : 0;
     for (uint32_t base = blockIdx.x * kBlock; base < n; base += gridDim.x * kBlock) {
@@ -822,14 +835,15 @@ __global__ __launch_bounds__(kBlock, RT_TRACE_OCC) void k_trace_easy(SceneView s
 // four lanes per ray, see namespace quad.  Rays the quad walk cannot finish (degenerate (ray, mesh) pairs,
 // stack overflow) go to the redo list and are re-traced by k_trace<false, true>.
 template <bool COUNT>
-__global__ __launch_bounds__(kBlock, RT_QUAD_OCC) void k_trace_quad(SceneView sv, FrameParams fp, Work w, uint32_t level) {
+__global__ __launch_bounds__(kBlock, RT_QUAD_OCC) void k_trace_quad(SceneView sv, FrameParams fp, Work w, uint32_t level,
+                                                                     uint32_t stack_cap) {
     const uint32_t q = threadIdx.x & 3u, g = threadIdx.x >> 2;
     quad::Stack qs;
-    qs.w = lds_dyn + g * quad::kStride;
-    qs.t = reinterpret_cast<float *>(lds_dyn + quad::kRaysPerBlock * quad::kStride) + g * quad::kStride;
+    qs.cap = stack_cap;
+    qs.e = reinterpret_cast<uint2 *>(lds_dyn) + g * (stack_cap + 1u);
     const uint32_t n = w.hard_count[0];
     const uint32_t n_shadow = fp.renderer == RTHIP_RENDER_RAYTRACER ? sv.n_lights : 0u;  // DebugRaycaster: closest hit only
-    KdCounters kc = {0, 0, 0, 0, 0, 0, 0, 0};
+    KdCounters kc = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t max_ray_nodes = 0;
     const long long t_start = COUNT ? clock64() : 0;
     for (uint32_t base = blockIdx.x * quad::kRaysPerBlock; base < n; base += gridDim.x * quad::kRaysPerBlock) {
@@ -1043,7 +1057,7 @@ struct rthip_ctx {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     DevBuf bvh_nodes, bvh_tris, bvh_index, kd_planes;
-    uint32_t stack_cap_kd = 1, stack_cap_bvh = 1, stack_cap_full = 1;
+    uint32_t stack_cap_kd = 1, stack_cap_bvh = 1, stack_cap_full = 1, bvh_depth = 0;
     DevBuf shapes, meshes, kd_nodes, kd_bounds, kd_refs, tris, tri_normals, materials, noises, perlin, worley, lights;
     SceneView sv;
     bool has_scene = false;
@@ -1293,6 +1307,7 @@ int rthip_upload_scene(rthip_ctx *c, const rthip_scene_desc *s) {
     c->has_meshes = s->n_meshes > 0;
     v.bg = s->background;
     c->stack_cap_kd = max_depth + 2;
+    c->bvh_depth = max_bvh_depth;
     c->stack_cap_bvh = 3 * max_bvh_depth + 2;  // one ray per lane over the 4-wide BVH: up to three pending children per level
     c->stack_cap_full = (max_depth + 2 > c->stack_cap_bvh ? max_depth + 2 : c->stack_cap_bvh);  // degenerate rays walk the kd-tree
     c->stack_cap = c->stack_cap_full;
@@ -1390,7 +1405,12 @@ static int render_frame(rthip_ctx *c, const rthip_camera *cam, const rthip_param
         HIP_TRY(hipFuncSetAttribute((const void *)k_trace<false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     }
     // hot kernel: one short stack per quad (child word + entry parameter per entry); deeper rays overflow into the redo list
-    const size_t lds_quad = (size_t)quad::kRaysPerBlock * quad::kStride * sizeof(uint32_t) * 2;
+    const uint32_t quad_cap = 3 * c->bvh_depth + 1;  // cannot overflow, see quad::Stack
+    const size_t lds_quad = (size_t)quad::kRaysPerBlock * (quad_cap + 1) * sizeof(uint2);
+    if (lds_quad > 64 * 1024) {
+        HIP_TRY(hipFuncSetAttribute((const void *)k_trace_quad<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_quad));
+        HIP_TRY(hipFuncSetAttribute((const void *)k_trace_quad<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_quad));
+    }
     const size_t lds_tables = (size_t)c->n_tables * 256;
 
     HIP_TRY(hipMemsetAsync(w.stats, 0, sizeof(unsigned long long) * ST_COUNT, c->stream));
@@ -1434,9 +1454,9 @@ static int render_frame(rthip_ctx *c, const rthip_camera *cam, const rthip_param
                     uint32_t qgrid = (fp.N0 + quad::kRaysPerBlock - 1) / quad::kRaysPerBlock;
                     if (qgrid > kMaxGridQuad) qgrid = kMaxGridQuad;
                     if (c->count_kd)
-                        hipLaunchKernelGGL((k_trace_quad<true>), dim3(qgrid), dim3(kBlock), lds_quad, c->stream, c->sv, fp, w, level);
+                        hipLaunchKernelGGL((k_trace_quad<true>), dim3(qgrid), dim3(kBlock), lds_quad, c->stream, c->sv, fp, w, level, quad_cap);
                     else
-                        hipLaunchKernelGGL((k_trace_quad<false>), dim3(qgrid), dim3(kBlock), lds_quad, c->stream, c->sv, fp, w, level);
+                        hipLaunchKernelGGL((k_trace_quad<false>), dim3(qgrid), dim3(kBlock), lds_quad, c->stream, c->sv, fp, w, level, quad_cap);
                 }
                 if (c->profile_launches) HIP_TRY(hipEventRecord(eb, c->stream));
                 if (c->has_meshes) {  // re-trace of the (rare) rays lying exactly in a kd split plane or overflowing the short stack
@@ -1517,6 +1537,7 @@ static int finish_stats(rthip_ctx *c, const rthip_params *p) {
     c->last.wave_steps = st[ST_WAVE_STEPS];
     c->last.wave_tris = st[ST_WAVE_TRIS];
     c->last.wave_cycles_max = st[ST_WAVE_CYCLES_MAX];
+    c->last.fetch_cycles = st[ST_FETCH_CYCLES];
     uint32_t lr[RTHIP_MAX_RECURSION + 1];
     HIP_TRY(hipMemcpy(lr, c->counts.p, sizeof lr, hipMemcpyDeviceToHost));
     memset(c->last.level_ms_trace, 0, sizeof c->last.level_ms_trace);

@@ -39,7 +39,7 @@ class Stats(C.Structure):
                 ("kd_tris_tested", C.c_uint64), ("kd_leaves_visited", C.c_uint64), ("kd_pops", C.c_uint64),
                 ("shape_tests", C.c_uint64), ("mesh_hits", C.c_uint64), ("kd_max_nodes_ray", C.c_uint64),
                 ("wave_steps_max", C.c_uint64), ("wave_tris_max", C.c_uint64), ("wave_steps", C.c_uint64), ("wave_tris", C.c_uint64),
-                ("wave_cycles_max", C.c_uint64),
+                ("wave_cycles_max", C.c_uint64), ("fetch_cycles", C.c_uint64),
                 ("level_rays", C.c_uint32 * 17), ("level_ms_trace", C.c_float * 17), ("level_ms_shade", C.c_float * 17)]
 
 
