@@ -9,7 +9,7 @@ region; every step traces the whole frame.  With N > 1 the frame is partitioned 
 HBM, the buffers are all-gathered over RCCL and assembled into the frame on the device; total work
 is fixed as N grows ("strong" scaling).
 
-Prints ONE JSON line (rank 0).  Extra objects: "roofline" (dominant kernel k_trace, algorithmic
+Prints ONE JSON line (rank 0).  Extra objects: "roofline" (dominant kernel k_trace_quad, algorithmic
 bytes from SURVEY.md §8d's per-ray formula with counts measured on this frame) and "cpu_baseline"
 (the genuine reference compiled in oracle/_ref — or the C oracle port — timed on the host cores).
 """
@@ -27,13 +27,23 @@ W, H, MAX_REC = 1920, 1080, 3
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s peak (spec)
 
 
-def algorithmic_bytes(st, pixels):
-    """B = 16*N_node + 4*N_ref + 128*N_tri + 72*[mesh hit] + 96*N_shape + 2*64*rays' + 4*pixels,
-    plus 48 B of stored bounds per resumed subtree (this implementation recomputes the six slab
-    parameters from them on a stack pop).  rays' = rays that went through a queue record."""
-    rays = st.rays_primary + st.rays_shadow + st.rays_reflect
-    return (16 * st.kd_nodes_visited + 48 * st.kd_pops + (128 + 4) * st.kd_tris_tested + 72 * st.mesh_hits +
-            96 * st.shape_tests + 2 * 64 * st.rays_reflect + 32 * (st.rays_primary + st.rays_reflect) + 4 * pixels), rays
+def algorithmic_bytes(st):
+    """Algorithmic bytes of the DOMINANT kernel (k_trace_quad: the mesh walk of the rays that need one), SURVEY.md
+    §8(d) restated for this implementation's records: 128 B per BVH node step (one line per ray and step), 128 + 4 B
+    per triangle tested (record + index), 72 B of vertex normals per mesh hit, 2 x 96 B of matrices per shape-table
+    entry tested, 64 B ray record in + 64 B hit record out per ray it traces."""
+    return (128 * st.kd_nodes_visited + 132 * st.kd_tris_tested + 72 * st.mesh_hits + 192 * st.shape_tests + 128 * st.rays_hard)
+
+
+def measured_traffic(launches):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/r01_pmc_traffic.json,
+    produced by tools/prof_traffic.sh: separate rocprofv3 --pmc runs of FETCH_SIZE and WRITE_SIZE over this very
+    workload, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950)."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if not os.path.exists(path):
+        return None
+    t = json.load(open(path))
+    return t.get("k_trace_quad_bytes_per_launch")
 
 
 def cpu_baseline(sd, max_seconds=25.0):
@@ -101,7 +111,8 @@ def main():
     gathered = torch.zeros(part_px * world, dtype=torch.int32, device="cuda") if world > 1 else None
     cctx.render_device(cam, prm, mine.data_ptr(), sync=True)
     cst = cctx.stats()
-    abytes, my_rays = algorithmic_bytes(cst, cst.pixels)
+    abytes = algorithmic_bytes(cst)
+    my_rays = cst.rays_primary + cst.rays_shadow + cst.rays_reflect
     cctx.close()
 
     os.environ["RTHIP_PROFILE_LAUNCHES"] = "1"
@@ -158,11 +169,11 @@ def main():
                        "partition": f"interleaved 32x8 screen tiles over {world} GPU(s)" + (", RCCL all-gather + device assemble" if world > 1 else ""),
                        "frame_checksum": checksum},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "k_trace", "launches_per_frame": int(st.launches_trace), "avg_launch_ms": launch_ms,
-                         "algorithmic_bytes_per_frame_rank0": int(abytes),
-                         "note": "the whole flattened bunny tree (~1.5 MB) is L2-resident: the kernel is fp64-VALU/latency bound, "
-                                 "not HBM bound; see DESIGN.md"},
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(st.launches_trace),
+                         "kernel": "k_trace_quad", "launches_per_frame": int(st.launches_trace), "avg_launch_ms": launch_ms,
+                         "algorithmic_bytes_per_frame_rank0": int(abytes), "rays_traced_by_kernel_per_frame_rank0": int(cst.rays_hard),
+                         "note": "the flattened bunny BVH (~0.8 MB) is L2-resident: the kernel is bound by the dependent-step "
+                                 "latency of its slowest wave, not by HBM; see DESIGN.md"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sd)

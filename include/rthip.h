@@ -227,8 +227,9 @@ typedef struct {
     uint64_t rays_primary, rays_shadow, rays_reflect;  /* Scene::CastRay-equivalent queries of the last render */
     uint64_t pixels;                                   /* pixels rendered by this context */
     float ms_total;                                    /* device time of the last render (HIP events) */
-    float ms_trace;                                    /* summed duration of the trace/shade kernels */
-    uint32_t launches_trace;                           /* number of trace/shade kernel launches */
+    float ms_trace;                                    /* summed duration of the dominant kernel (RTHIP_PROFILE_LAUNCHES=1): the
+                                                        * mesh-walk kernel k_trace_quad (accel = 0) or k_trace (accel = 1) */
+    uint32_t launches_trace;                           /* number of launches of that kernel (= recursion levels traced) */
     uint32_t pad;
     /* only collected by contexts created with RTHIP_COUNTERS=1 in the environment: */
     uint64_t kd_nodes_visited;   /* kd node records fetched (16 B each) */
@@ -245,10 +246,16 @@ typedef struct {
     uint64_t wave_cycles_max;    /* longest-lived trace wave of the frame, shader clock cycles */
     uint64_t fetch_cycles;       /* cycles waves waited for BVH node fetches (RTHIP_COUNTERS=2: of the longest wave) */
     /* per recursion level of the last chunk: rays in the level's queue, and (RTHIP_PROFILE_LAUNCHES=1)
-     * the duration of the level's trace kernels and of its shade kernel */
+     * the duration of the level's dominant trace kernel, of the kernels after it (redo + shade of the
+     * listed rays) and of k_trace_easy (which also shades the rays it finishes) */
     uint32_t level_rays[RTHIP_MAX_RECURSION + 1];
     float level_ms_trace[RTHIP_MAX_RECURSION + 1];
     float level_ms_shade[RTHIP_MAX_RECURSION + 1];
+    float level_ms_easy[RTHIP_MAX_RECURSION + 1];
+    float ms_easy;               /* summed duration of k_trace_easy */
+    uint32_t pad2;
+    uint64_t rays_hard;          /* rays (all levels) that needed a mesh walk = rays traced by the dominant kernel */
+    uint64_t shape_tests_easy;   /* RTHIP_COUNTERS=1: shape-table entries tested by k_trace_easy (shape_tests: by the dominant kernel) */
 } rthip_stats;
 
 /* ---- lifecycle ---- */

@@ -78,7 +78,7 @@ static const uint32_t kBlock = 256;           // 4 waves per workgroup
 #endif
 static const uint32_t kMaxGridQuad = 16384;    // same for the quad kernel (64 rays per workgroup)
 static const uint32_t kMaxGridLevel = 4096;   // queue levels: grid-stride over a bounded grid
-enum { ST_KD_NODES = 0, ST_KD_TRIS, ST_KD_LEAVES, ST_KD_POPS, ST_SHAPES, ST_MESH_HITS, ST_KD_MAXRAY, ST_WAVE_STEPS_MAX, ST_WAVE_TRIS_MAX, ST_WAVE_STEPS, ST_WAVE_TRIS, ST_WAVE_CYCLES_MAX, ST_FETCH_CYCLES, ST_COUNT };
+enum { ST_KD_NODES = 0, ST_KD_TRIS, ST_KD_LEAVES, ST_KD_POPS, ST_SHAPES, ST_MESH_HITS, ST_KD_MAXRAY, ST_WAVE_STEPS_MAX, ST_WAVE_TRIS_MAX, ST_WAVE_STEPS, ST_WAVE_TRIS, ST_WAVE_CYCLES_MAX, ST_FETCH_CYCLES, ST_SHAPES_EASY, ST_COUNT };
 
 // Per-frame constants
 struct FrameParams {
@@ -828,7 +828,11 @@ __global__ __launch_bounds__(kBlock, RT_TRACE_OCC) void k_trace_easy(SceneView s
         shade_and_spawn(sv, fp, w, tabs, sh, level, live && done, i, h, d, shadow_total, spawn_total);
     }
     shade_stats_flush(w, sh, 0, level, levels, shadow_total, spawn_total);
-    if (COUNT) trace_counters_flush(fp, w, kc, 0, t_start);
+    if (COUNT) {
+        kc.shapes = wave_sum(kc.shapes);
+        if ((threadIdx.x & 63u) == 0 && kc.shapes && fp.count_kd != 2) atomicAdd(&w.stats[ST_SHAPES_EASY], (unsigned long long)kc.shapes);
+        (void)t_start;
+    }
 }
 
 // Stage 1b of a level for the BVH path (accel = 0): the rays k_trace_easy listed as needing a mesh walk,
@@ -1438,9 +1442,9 @@ static int render_frame(rthip_ctx *c, const rthip_camera *cam, const rthip_param
         for (uint32_t level = 0; level < levels; level++) {
             uint32_t grid = (fp.N0 + kBlock - 1) / kBlock;
             if (level > 0 && grid > kMaxGridLevel) grid = kMaxGridLevel;
-            hipEvent_t ea = nullptr, eb = nullptr, ec = nullptr;
+            hipEvent_t ea = nullptr, eq = nullptr, eb = nullptr, ec = nullptr;
             if (c->profile_launches) {
-                if (get_event(&ea) || get_event(&eb) || get_event(&ec)) return RTHIP_E_HIP;
+                if (get_event(&ea) || get_event(&eq) || get_event(&eb) || get_event(&ec)) return RTHIP_E_HIP;
                 HIP_TRY(hipEventRecord(ea, c->stream));
             }
             w.redo_count = w.counts + (RTHIP_MAX_RECURSION + 3) + level;
@@ -1450,6 +1454,7 @@ static int render_frame(rthip_ctx *c, const rthip_camera *cam, const rthip_param
                     hipLaunchKernelGGL((k_trace_easy<true>), dim3(grid), dim3(kBlock), lds_tables, c->stream, c->sv, fp, w, level, c->n_tables, levels);
                 else
                     hipLaunchKernelGGL((k_trace_easy<false>), dim3(grid), dim3(kBlock), lds_tables, c->stream, c->sv, fp, w, level, c->n_tables, levels);
+                if (c->profile_launches) HIP_TRY(hipEventRecord(eq, c->stream));
                 if (c->has_meshes) {  // the rays that need a mesh walk (count on the device: the grid is an upper bound, strided)
                     uint32_t qgrid = (fp.N0 + quad::kRaysPerBlock - 1) / quad::kRaysPerBlock;
                     if (qgrid > kMaxGridQuad) qgrid = kMaxGridQuad;
@@ -1466,6 +1471,7 @@ static int render_frame(rthip_ctx *c, const rthip_camera *cam, const rthip_param
                         hipLaunchKernelGGL((k_trace<false, true, false>), dim3(64), dim3(kBlock), lds_bytes, c->stream, c->sv, fp, w, level, c->stack_cap);
                 }
             } else {
+                if (c->profile_launches) HIP_TRY(hipEventRecord(eq, c->stream));
                 if (c->count_kd)
                     hipLaunchKernelGGL((k_trace<false, false, true>), dim3(grid), dim3(kBlock), lds_bytes, c->stream, c->sv, fp, w, level, c->stack_cap);
                 else
@@ -1495,7 +1501,7 @@ static int render_frame(rthip_ctx *c, const rthip_camera *cam, const rthip_param
         HIP_TRY(hipStreamSynchronize(c->stream));
         return fail(RTHIP_E_INTERRUPTED, "rthip_render: interrupted");
     }
-    c->last.launches_trace = (uint32_t)(ev_used / 3);
+    c->last.launches_trace = (uint32_t)(ev_used / 4);
     return 0;
 }
 
@@ -1538,6 +1544,14 @@ static int finish_stats(rthip_ctx *c, const rthip_params *p) {
     c->last.wave_tris = st[ST_WAVE_TRIS];
     c->last.wave_cycles_max = st[ST_WAVE_CYCLES_MAX];
     c->last.fetch_cycles = st[ST_FETCH_CYCLES];
+    c->last.shape_tests_easy = st[ST_SHAPES_EASY];
+    {
+        uint32_t hc[RTHIP_MAX_RECURSION + 1];
+        HIP_TRY(hipMemcpy(hc, (const uint32_t *)c->counts.p + 2 * (RTHIP_MAX_RECURSION + 3), sizeof hc, hipMemcpyDeviceToHost));
+        uint64_t hard = 0;
+        for (uint32_t i = 0; i <= p->max_recursion && i <= RTHIP_MAX_RECURSION; i++) hard += hc[i];
+        c->last.rays_hard = p->accel == 0 ? hard : 0;  // last chunk only (frames of <= 2^24 rays per level are one chunk)
+    }
     uint32_t lr[RTHIP_MAX_RECURSION + 1];
     HIP_TRY(hipMemcpy(lr, c->counts.p, sizeof lr, hipMemcpyDeviceToHost));
     memset(c->last.level_ms_trace, 0, sizeof c->last.level_ms_trace);
@@ -1545,18 +1559,23 @@ static int finish_stats(rthip_ctx *c, const rthip_params *p) {
     for (uint32_t i = 0; i <= RTHIP_MAX_RECURSION; i++) c->last.level_rays[i] = i <= p->max_recursion ? lr[i] : 0;
     c->last.level_rays[0] = (uint32_t)c->last.rays_primary;
     c->last.ms_total = ms;
-    float sum = 0.f;
+    float sum = 0.f, sum_easy = 0.f;
+    memset(c->last.level_ms_easy, 0, sizeof c->last.level_ms_easy);
     for (uint32_t i = 0; i < c->last.launches_trace; i++) {
-        float t = 0.f, u = 0.f;
-        HIP_TRY(hipEventElapsedTime(&t, c->ev_pool[3 * i], c->ev_pool[3 * i + 1]));
-        HIP_TRY(hipEventElapsedTime(&u, c->ev_pool[3 * i + 1], c->ev_pool[3 * i + 2]));
+        float e = 0.f, t = 0.f, u = 0.f;
+        HIP_TRY(hipEventElapsedTime(&e, c->ev_pool[4 * i], c->ev_pool[4 * i + 1]));
+        HIP_TRY(hipEventElapsedTime(&t, c->ev_pool[4 * i + 1], c->ev_pool[4 * i + 2]));
+        HIP_TRY(hipEventElapsedTime(&u, c->ev_pool[4 * i + 2], c->ev_pool[4 * i + 3]));
         sum += t;
+        sum_easy += e;
         if (i <= RTHIP_MAX_RECURSION) {  // single-chunk frames: launch i = level i
+            c->last.level_ms_easy[i] = e;
             c->last.level_ms_trace[i] = t;
             c->last.level_ms_shade[i] = u;  // includes the (normally empty) redo kernel
         }
     }
     c->last.ms_trace = sum;
+    c->last.ms_easy = sum_easy;
     c->progress.store(1.f);
     return 0;
 }

@@ -40,7 +40,8 @@ class Stats(C.Structure):
                 ("shape_tests", C.c_uint64), ("mesh_hits", C.c_uint64), ("kd_max_nodes_ray", C.c_uint64),
                 ("wave_steps_max", C.c_uint64), ("wave_tris_max", C.c_uint64), ("wave_steps", C.c_uint64), ("wave_tris", C.c_uint64),
                 ("wave_cycles_max", C.c_uint64), ("fetch_cycles", C.c_uint64),
-                ("level_rays", C.c_uint32 * 17), ("level_ms_trace", C.c_float * 17), ("level_ms_shade", C.c_float * 17)]
+                ("level_rays", C.c_uint32 * 17), ("level_ms_trace", C.c_float * 17), ("level_ms_shade", C.c_float * 17), ("level_ms_easy", C.c_float * 17),
+                ("ms_easy", C.c_float), ("pad2", C.c_uint32), ("rays_hard", C.c_uint64), ("shape_tests_easy", C.c_uint64)]
 
 
 class RthipError(RuntimeError):

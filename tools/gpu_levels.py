@@ -24,6 +24,7 @@ for cfg in cfgs:
               f"nodes={s.kd_nodes_visited} tris={s.kd_tris_tested} leaves={s.kd_leaves_visited} pops={s.kd_pops}\n"
               f"   wave steps max={s.wave_steps_max} total={s.wave_steps}  wave tri-iters max={s.wave_tris_max} total={s.wave_tris}  longest wave {s.wave_cycles_max} cycles; node-fetch wait {s.fetch_cycles} cycles = {s.fetch_cycles / max(1, s.wave_steps):.0f}/step")
         print("   level rays:", list(s.level_rays[:mr + 1]))
-        print("   trace ms  :", [round(x, 3) for x in s.level_ms_trace[:mr + 1]])
+        print("   easy ms   :", [round(x, 3) for x in s.level_ms_easy[:mr + 1]], " hard rays:", s.rays_hard)
+        print("   quad ms   :", [round(x, 3) for x in s.level_ms_trace[:mr + 1]])
         print("   shade ms  :", [round(x, 3) for x in s.level_ms_shade[:mr + 1]], flush=True)
         ctx.close()
