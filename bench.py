@@ -77,6 +77,8 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--inflight", type=int, default=3, help="frames in flight (one context + HIP stream each)")
+    ap.add_argument("--force-gather", action="store_true", help="run the RCCL gather + assemble path even with one rank")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -92,13 +94,17 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    elif args.force_gather:  # rehearsal of the multi-GPU data path on one GPU
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29517", rank=0, world_size=1,
+                                device_id=torch.device("cuda", local_rank))
 
     from raytracing_amd import device, host, scenes
     sd, _ = scenes.config(3)
     hs = host.HostScene(sd, device_index=local_rank)
     desc = hs.flatten()
     cam = hs.camera(W, H)
-    prm = device.make_params(W, H, MAX_REC, part_index=rank, part_count=world, layout=1 if world > 1 else 0)
+    gather = world > 1 or args.force_gather
+    prm = device.make_params(W, H, MAX_REC, part_index=rank, part_count=world, layout=1 if gather else 0)
 
     # one untimed frame on a counting context: per-frame ray and kd-traversal counts (this rank's share)
     os.environ["RTHIP_COUNTERS"] = "1"
@@ -107,45 +113,79 @@ def main():
     cctx.upload(desc)
     part_px = device.part_pixels(prm)
     frame = torch.zeros(W * H, dtype=torch.int32, device="cuda")
-    mine = torch.zeros(part_px, dtype=torch.int32, device="cuda") if world > 1 else frame
-    gathered = torch.zeros(part_px * world, dtype=torch.int32, device="cuda") if world > 1 else None
+    mine = torch.zeros(part_px, dtype=torch.int32, device="cuda") if gather else frame
     cctx.render_device(cam, prm, mine.data_ptr(), sync=True)
     cst = cctx.stats()
     abytes = algorithmic_bytes(cst)
     my_rays = cst.rays_primary + cst.rays_shadow + cst.rays_reflect
     cctx.close()
 
-    os.environ["RTHIP_PROFILE_LAUNCHES"] = "1"
-    ctx = device.Context(local_rank)
-    ctx.upload(desc)
+    # Timed contexts: `inflight` frames are in flight at once, each on its own context (own HIP stream, own
+    # workspace, own output buffers), so that the latency-bound tail of one frame's kernels overlaps with the
+    # next frame's work.  Every frame is traced completely; frame k uses context k % inflight.
+    F = max(1, args.inflight)
+    ctxs, mines, gathers, frames, exts = [], [], [], [], []
+    for k in range(F):
+        c = device.Context(local_rank)
+        c.upload(desc)
+        ctxs.append(c)
+        fr = frame if k == 0 else torch.zeros(W * H, dtype=torch.int32, device="cuda")
+        frames.append(fr)
+        mines.append(torch.zeros(part_px, dtype=torch.int32, device="cuda") if gather else fr)
+        gathers.append(torch.zeros(part_px * world, dtype=torch.int32, device="cuda") if gather else None)
+        exts.append(torch.cuda.ExternalStream(c.stream()))
+    comm = torch.cuda.current_stream()
 
-    def step():
-        ctx.render_device(cam, prm, mine.data_ptr(), sync=False)
-        if world > 1:
-            ctx.synchronize()  # the gather runs on torch's stream
-            dist.all_gather_into_tensor(gathered, mine)
-            torch.cuda.current_stream().synchronize()
-            ctx.assemble(prm, gathered.data_ptr(), frame.data_ptr(), sync=False)
+    def step(k):
+        j = k % F
+        c = ctxs[j]
+        c.render_device(cam, prm, mines[j].data_ptr(), sync=False)
+        if gather:  # device-side ordering only: render -> RCCL all-gather (torch's stream) -> assemble (context's stream)
+            done = torch.cuda.Event()
+            done.record(exts[j])
+            comm.wait_event(done)
+            dist.all_gather_into_tensor(gathers[j], mines[j])
+            gathered_ev = torch.cuda.Event()
+            gathered_ev.record(comm)
+            exts[j].wait_event(gathered_ev)
+            c.assemble(prm, gathers[j].data_ptr(), frames[j].data_ptr(), sync=False)
 
     def sync_all():
-        ctx.synchronize()
+        for c in ctxs:
+            c.synchronize()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    for k in range(args.warmup):
+        step(k)
     sync_all()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    for k in range(args.steps):
+        step(k)
     sync_all()
     dt = time.perf_counter() - t0
 
-    # per-launch duration of the dominant kernel (HIP events on the context's own stream), last frame
-    ctx.render_device(cam, prm, mine.data_ptr(), sync=True)
-    st = ctx.stats()
+    # latency of ONE frame (nothing else in flight), and the per-launch duration of the dominant kernel
+    # (HIP events on the context's own stream) on a profiling context
+    lat = []
+    for _ in range(10):
+        t1 = time.perf_counter()
+        step(0)
+        sync_all()
+        lat.append((time.perf_counter() - t1) * 1e3)
+    lat.sort()
+    for c in ctxs[1:]:
+        c.close()
+    os.environ["RTHIP_PROFILE_LAUNCHES"] = "1"
+    pctx = device.Context(local_rank)
+    os.environ["RTHIP_PROFILE_LAUNCHES"] = "0"
+    pctx.upload(desc)
+    for _ in range(3):
+        pctx.render_device(cam, prm, mines[0].data_ptr(), sync=True)
+    st = pctx.stats()
+    pctx.close()
     launch_ms = st.ms_trace / max(1, st.launches_trace)
     total_rays = torch.tensor([float(my_rays), dt], dtype=torch.float64, device="cuda")
     if world > 1:
@@ -154,7 +194,7 @@ def main():
         rays_frame, dt = float(rays_t.item()), float(dt_t.item())
     else:
         rays_frame = float(my_rays)
-    checksum = int(frame.to(torch.int64).sum().item()) if rank == 0 else 0
+    checksum = int(frames[0].to(torch.int64).sum().item()) if rank == 0 else 0
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
@@ -166,7 +206,8 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "BASELINE configs[2]: Demo 4 bunny.obj (4968 tris, kd-tree) + checker plane + SkyBox sun, "
                                    "1920x1080, MaxRecursion 3, camera (0,0,5)", "rays_per_frame": int(rays_frame),
-                       "partition": f"interleaved 32x8 screen tiles over {world} GPU(s)" + (", RCCL all-gather + device assemble" if world > 1 else ""),
+                       "partition": f"interleaved 32x8 screen tiles over {world} GPU(s)" + (", RCCL all-gather + device assemble" if gather else ""),
+                       "frames_in_flight": F, "single_frame_latency_ms": lat[len(lat) // 2],
                        "frame_checksum": checksum},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(st.launches_trace),
@@ -178,7 +219,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sd)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 
