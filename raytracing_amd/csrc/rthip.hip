@@ -1,17 +1,20 @@
 // rthip.hip — HIP kernels (gfx950 / CDNA4) + C-ABI of the Raycast hot path.  See include/rthip.h.
 //
-// Frame pipeline (wavefront style, one ray per lane, 64-lane waves):
-//   k_trace level k  : every scene query of the level — closest hit (level 0 generates its rays)
-//                      and one shadow query per light; traversal code only, hit records out.
-//   k_shade level k  : material / noise / background, Lambert terms, reflected rays compacted
-//                      into the level-(k+1) queue with a wave ballot + prefix popcount and ONE
-//                      atomic per workgroup.  Level counts are read from device memory, so the
-//                      host never synchronises between levels.
-//   k_fold level k   : C_{k-1} = direct_{k-1} (+) C_k (x) refl_{k-1}  (clamping Color algebra forbids a
-//                      forward throughput product), back to front.
-//   k_resolve        : level-0 colours -> 0xAABBGGRR pixels (and the 3x3 SSAA sum).
-// kd-tree traversal keeps its per-lane stack of pending subtrees in LDS (lane-interleaved, so
-// pushes/pops of a wave are bank-conflict free).  No MFMA: the path is divergent fp64 VALU work.
+// Frame pipeline, per recursion level k (wavefront style; ray counts stay on the device, the host never
+// synchronises between levels):
+//   k_trace_easy     : one ray per lane.  Level 0 generates its rays.  Every query of the ray over the
+//                      analytic shapes; meshes only through a conservative test of their BVH root boxes.
+//                      Rays that cannot touch a mesh are finished AND shaded here (material / noise /
+//                      background, Lambert terms, reflected ray compacted into the level-(k+1) queue with a
+//                      wave ballot + prefix popcount and ONE atomic per workgroup); the others are listed.
+//   k_trace_quad     : the listed rays, FOUR LANES PER RAY over the 4-wide BVH (namespace quad), exact fp64
+//                      triangle tests; writes hit records.
+//   k_trace<.,true>  : redo list (rays only the reference kd-tree reproduces); normally empty.
+//   k_shade<true>    : shading + spawn of the listed rays from their hit records.
+// then k_resolve: per pixel, C_k = direct_k (+) C_{k+1} (x) refl_k folded back to front along the pixel's
+// chain of rays (clamping Color algebra forbids a forward throughput product), 3x3 SSAA
+// sum, 0xAABBGGRR pack.  accel = 1 runs k_trace<false,false> + k_shade<false> instead (reference kd-tree,
+// one ray per lane).  No MFMA: the path is divergent fp64 VALU work.
 //
 // Built with -ffp-contract=off: the oracle is the non-fused x86-64 build of the reference.
 #include <hip/hip_runtime.h>
