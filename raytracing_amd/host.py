@@ -36,6 +36,10 @@ def load_host():
         L.rehost_job_interrupt.argtypes = [C.c_void_p]; L.rehost_job_interrupt.restype = None
         L.rehost_job_wait.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]
         L.rehost_job_free.argtypes = [C.c_void_p]; L.rehost_job_free.restype = None
+        L.rehost_scene_from_script.argtypes = [C.c_char_p, C.c_char_p]; L.rehost_scene_from_script.restype = C.c_void_p
+        L.rehost_scenes_xml.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_char_p, C.c_int]
+        L.rehost_load_obj.argtypes = [C.c_char_p, C.c_char_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.rehost_write_ppm.argtypes = [C.c_char_p, C.c_void_p, C.c_int, C.c_int]
         _host = sb
     return _host
 
@@ -49,6 +53,21 @@ class HostScene:
         self.L = self.sb.lib
         self.h = self.built.h
         self.L.rehost_set_device(self.h, device_index)
+
+    @classmethod
+    def from_script(cls, code, res_dir="", device_index=0):
+        """A scene evaluated by the product's scene-script reader (host/scene_io.cpp: the reXxx call subset of the
+        reference's Sandbox scripts, Sandbox.cpp:578-763)."""
+        self = cls.__new__(cls)
+        self.sb = load_host()
+        self.L = self.sb.lib
+        h = self.L.rehost_scene_from_script(code.encode(), res_dir.encode())
+        if not h:
+            raise RuntimeError("scene script: " + self.L.rehost_last_error().decode())
+        self.built = BuiltScene(self.sb, h)
+        self.h = self.built.h
+        self.L.rehost_set_device(self.h, device_index)
+        return self
 
     def set_accel(self, use_reference_kd):
         self.L.rehost_set_accel(self.h, int(bool(use_reference_kd)))
@@ -108,3 +127,36 @@ class RenderJob:
         if self.j:
             self.hs.L.rehost_job_free(self.j)
             self.j = None
+
+
+def scenes_xml(path):
+    """[(name, code)] of a scenes.xml store (Sandbox/res/scenes.xml format) read by the product's reader."""
+    L = load_host().lib
+    n = L.rehost_scenes_xml(path.encode(), -1, None, 0, None, 0)
+    if n < 0:
+        raise RuntimeError(L.rehost_last_error().decode())
+    out = []
+    for i in range(n):
+        name = C.create_string_buffer(1 << 10)
+        code = C.create_string_buffer(1 << 20)
+        L.rehost_scenes_xml(path.encode(), i, name, len(name), code, len(code))
+        out.append((name.value.decode(), code.value.decode()))
+    return out
+
+
+def load_obj(path, group):
+    """(verts, normals) float64 [n, 9] of an OBJ group as reObjMesh takes them (product's Wavefront reader)."""
+    L = load_host().lib
+    n = L.rehost_load_obj(path.encode(), group.encode(), None, None, 0)
+    if n < 0:
+        raise RuntimeError(L.rehost_last_error().decode())
+    v = np.zeros((n, 9)); nr = np.zeros((n, 9))
+    L.rehost_load_obj(path.encode(), group.encode(), v.ctypes.data_as(C.c_void_p), nr.ctypes.data_as(C.c_void_p), n)
+    return v, nr
+
+
+def write_ppm(path, pixels):
+    px = np.ascontiguousarray(pixels, dtype=np.uint32)
+    L = load_host().lib
+    if L.rehost_write_ppm(path.encode(), px.ctypes.data_as(C.c_void_p), px.shape[1], px.shape[0]) != 0:
+        raise RuntimeError(L.rehost_last_error().decode())

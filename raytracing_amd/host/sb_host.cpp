@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "flatten.hpp"
+#include "scene_io.hpp"
 #include "re/re.hpp"
 #include "rthip.h"
 
@@ -72,6 +73,70 @@ sb_scene *sb_scene_new(void) {
     return s;
 }
 void sb_scene_free(sb_scene *s) { delete s; }
+
+// scene inputs of the reference's Sandbox (scene_io.hpp): a scene from a script of the reXxx call subset
+sb_scene *rehost_scene_from_script(const char *code, const char *res_dir) {
+    try {
+        sbio::ScriptScene sc;
+        sbio::RunSceneScript(code ? code : "", res_dir ? res_dir : "", sc);
+        sb_scene *s = new sb_scene;
+        s->scene = sc.Scene;
+        s->nodes = sc.ShapeNodes;
+        s->mats = sc.Materials;
+        s->noises = sc.Noises;
+        s->lights = sc.Lights;
+        return s;
+    } catch (const std::exception &e) {
+        g_host_err = e.what();
+        return nullptr;
+    }
+}
+// scene `index` of a scenes.xml store: name and code copied into the caller's buffers; returns the number of scenes, -1 on error
+int rehost_scenes_xml(const char *path, int index, char *name, int name_cap, char *code, int code_cap) {
+    try {
+        auto scenes = sbio::ReadScenesXml(path);
+        if (index >= 0 && index < (int)scenes.size()) {
+            if (name && name_cap > 0) { std::strncpy(name, scenes[index].first.c_str(), name_cap - 1); name[name_cap - 1] = 0; }
+            if (code && code_cap > 0) { std::strncpy(code, scenes[index].second.c_str(), code_cap - 1); code[code_cap - 1] = 0; }
+        }
+        return (int)scenes.size();
+    } catch (const std::exception &e) {
+        g_host_err = e.what();
+        return -1;
+    }
+}
+// Wavefront OBJ group -> triangles (first three vertices / normals of every face, as reObjMesh takes them);
+// returns the triangle count (call with null buffers first), -1 on error
+int rehost_load_obj(const char *path, const char *group, double *verts9, double *normals9, int cap_tris) {
+    try {
+        auto data = sbio::LoadWavefront(path);
+        auto g = data.find(group);
+        if (g == data.end()) { g_host_err = std::string("Invalid obj group: ") + group; return -1; }
+        int n = 0;
+        for (const auto &f : g->second) {
+            if (f.Vertices.size() < 3) { g_host_err = "obj face with fewer than 3 vertices"; return -1; }
+            if (verts9 && normals9 && n < cap_tris)
+                for (int k = 0; k < 3; k++) {
+                    verts9[9 * n + 3 * k] = f.Vertices[k].X; verts9[9 * n + 3 * k + 1] = f.Vertices[k].Y; verts9[9 * n + 3 * k + 2] = f.Vertices[k].Z;
+                    normals9[9 * n + 3 * k] = f.Normals[k].X; normals9[9 * n + 3 * k + 1] = f.Normals[k].Y; normals9[9 * n + 3 * k + 2] = f.Normals[k].Z;
+                }
+            n++;
+        }
+        return n;
+    } catch (const std::exception &e) {
+        g_host_err = e.what();
+        return -1;
+    }
+}
+int rehost_write_ppm(const char *path, const uint32_t *pixels, int width, int height) {
+    try {
+        sbio::WritePPM(path, pixels, (size_t)width, (size_t)height);
+        return 0;
+    } catch (const std::exception &e) {
+        g_host_err = e.what();
+        return -1;
+    }
+}
 void sb_camera(sb_scene *s, const double pos[3], const double dir[3]) {
     s->scene->Camera.Position = V3(pos);
     s->scene->Camera.Direction = V3(dir);

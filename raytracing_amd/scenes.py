@@ -199,6 +199,20 @@ class SceneDesc:
     def skybox(self, rgb0, rgb1, sun, seed):
         self.ops.append(("bg_skybox", int(rgb0), int(rgb1), sun, perlin_table(seed)))
 
+    def adopt_tables(self, built):
+        """Replaces this description's noise tables by those of an already built scene (sbapi.BuiltScene) with the
+        same noises in the same order, e.g. one whose constructors drew them from rand() like the reference's."""
+        ni = 0
+        for k, op in enumerate(self.ops):
+            if op[0] in ("noise_checker", "noise_perlin", "noise_worley", "noise_marble"):
+                if op[0] in ("noise_perlin", "noise_marble"):
+                    self.ops[k] = op[:-1] + (built.perlin_table(ni),)
+                elif op[0] == "noise_worley":
+                    self.ops[k] = op[:-1] + (built.worley_points(ni, op[2]),)
+                ni += 1
+            elif op[0] == "bg_skybox":
+                self.ops[k] = op[:-1] + (built.skybox_table(),)
+
     # replay -------------------------------------------------------------------------
     def build(self, sblib):
         L = sblib.lib
