@@ -80,6 +80,7 @@ static const uint32_t kBlock = 256;           // 4 waves per workgroup
 #define RT_SHADE_OCC 4
 #endif
 static const uint32_t kMaxGridQuad = 16384;    // same for the quad kernel (64 rays per workgroup)
+static const size_t kMaxLevelRays = (size_t)1 << 24;  // level-0 rays per chunk (bounds the workspace); RTHIP_CHUNK_RAYS overrides (tests)
 static const uint32_t kMaxGridLevel = 4096;   // queue levels: grid-stride over a bounded grid
 enum { ST_KD_NODES = 0, ST_KD_TRIS, ST_KD_LEAVES, ST_KD_POPS, ST_SHAPES, ST_MESH_HITS, ST_KD_MAXRAY, ST_WAVE_STEPS_MAX, ST_WAVE_TRIS_MAX, ST_WAVE_STEPS, ST_WAVE_TRIS, ST_WAVE_CYCLES_MAX, ST_FETCH_CYCLES, ST_SHAPES_EASY, ST_COUNT };
 
@@ -1078,6 +1079,7 @@ struct rthip_ctx {
     std::atomic<float> progress{0.f};
     rthip_stats last{};
     int count_kd = 0;
+    size_t chunk_rays = kMaxLevelRays;
     int profile_launches = 0;
     std::vector<hipEvent_t> ev_pool;
 };
@@ -1110,6 +1112,8 @@ int rthip_create(int device, rthip_ctx **out) {
     }
     const char *env = getenv("RTHIP_COUNTERS");
     c->count_kd = env ? atoi(env) : 0;
+    env = getenv("RTHIP_CHUNK_RAYS");
+    if (env && atoll(env) > 0) c->chunk_rays = (size_t)atoll(env);
     env = getenv("RTHIP_PROFILE_LAUNCHES");
     c->profile_launches = env && atoi(env) != 0;
     memset(&c->sv, 0, sizeof c->sv);
@@ -1323,7 +1327,6 @@ int rthip_upload_scene(rthip_ctx *c, const rthip_scene_desc *s) {
 }
 
 // ---------------------------------------------------------------------------- frame
-static const size_t kMaxLevelRays = (size_t)1 << 24;  // level-0 rays per chunk (bounds the workspace)
 
 static int check_params(const rthip_camera *cam, const rthip_params *p) {
     if (!cam || !p) return fail(RTHIP_E_INVALID, "rthip_render: null argument");
@@ -1370,7 +1373,7 @@ static int render_frame(rthip_ctx *c, const rthip_camera *cam, const rthip_param
     const uint32_t per_tile = fp.tile_w * fp.tile_h;
     const uint32_t spp = fp.aa ? 9 : 1;
     const uint32_t levels = fp.max_rec + 1;
-    uint32_t tiles_per_chunk = (uint32_t)(kMaxLevelRays / ((size_t)per_tile * spp));
+    uint32_t tiles_per_chunk = (uint32_t)(c->chunk_rays / ((size_t)per_tile * spp));
     if (tiles_per_chunk == 0) tiles_per_chunk = 1;
     if (tiles_per_chunk > my_tiles) tiles_per_chunk = my_tiles ? my_tiles : 1;
     const size_t N = (size_t)tiles_per_chunk * per_tile * spp;

@@ -186,6 +186,28 @@ def test_multi_mesh_scene_matches_oracle(oracle_lib):
         assert (got["tri"] >= 0).mean() > 0.2          # the meshes fill a good part of the view
 
 
+def test_chunked_frames_are_identical(monkeypatch):
+    """frames larger than the per-level workspace are rendered chunk by chunk (8K x SSAA in production); forcing a
+    tiny chunk must not change a pixel or a ray count"""
+    sd = scenes.config(3, cam_z=2.5)[0]
+    hs = host.HostScene(sd)
+    desc, cam = hs.flatten(), hs.camera(320, 180)
+    out = {}
+    for chunk in ("0", "6000"):
+        monkeypatch.setenv("RTHIP_CHUNK_RAYS", chunk)
+        c = device.Context(0)
+        c.upload(desc)
+        for aa in (0, 1):
+            r = c.render(cam, device.make_params(320, 180, 3, aa=aa), ids=True)
+            st = c.stats()
+            out[chunk, aa] = (r["pixels"].copy(), r["shape"].copy(), r["tri"].copy(), st.rays_primary, st.rays_shadow, st.rays_reflect)
+        c.close()
+    for aa in (0, 1):
+        a, b = out["0", aa], out["6000", aa]
+        assert all(np.array_equal(x, y) for x, y in zip(a[:3], b[:3])) and a[3:] == b[3:]
+    assert out["0", 0][4] > 0 and out["0", 1][3] == 9 * out["0", 0][3]
+
+
 def test_tile_partition_is_bit_identical_and_assembles(ctx):
     """multi-GPU path on one GPU: every part rendered on its own (frame layout and tile-compact layout),
     then rthip_assemble; the result must equal the single-part frame bit for bit."""
