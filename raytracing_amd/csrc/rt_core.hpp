@@ -581,7 +581,8 @@ struct BvhRay {
 RT_HD float bvh_inv(double d) {
     float f = (float)d;
     float r = 1.0f / f;
-    const float big = 1e30f;  // keeps plane*inv - o*inv and pad*|inv| finite: no inf - inf
+    const float big = 1e18f;  // keeps plane*inv - o*inv and pad*|inv| finite (no inf - inf) up to |coordinate| ~ 1e20;
+                              // the slab widening pad*big still covers every parameter below 1e12 * scene magnitude
     if (!(fabsf(r) < big)) r = (f < 0.0f || (f == 0.0f && d < 0.0)) ? -big : big;
     return r;
 }

@@ -362,6 +362,32 @@ __device__ __forceinline__ bool tri_eval(const rthip_tri &t, V3 o, V3 d, double 
     return true;
 }
 
+// rtc::bvh_slab with the near / far plane of every axis picked by the sign of the ray direction (a select
+// instead of a min and a max) and the widening folded into the constants: near = fma(plane_near, inv, -(c + s)),
+// far = fma(plane_far, inv, s - c).  Same error budget as rtc::BvhRay (one rounding fewer per parameter).
+struct SlabRay {
+    float ix, iy, iz;
+    float nx, ny, nz;  // -(o*inv + widening)
+    float fx, fy, fz;  // widening - o*inv
+    bool sx, sy, sz;   // direction component negative: the near plane is `hi`
+};
+__device__ __forceinline__ SlabRay slab_ray(const BvhRay &r) {
+    SlabRay s;
+    s.ix = r.ix; s.iy = r.iy; s.iz = r.iz;
+    s.nx = -(r.cx + r.sx); s.ny = -(r.cy + r.sy); s.nz = -(r.cz + r.sz);
+    s.fx = r.sx - r.cx; s.fy = r.sy - r.cy; s.fz = r.sz - r.cz;
+    s.sx = r.ix < 0.0f; s.sy = r.iy < 0.0f; s.sz = r.iz < 0.0f;
+    return s;
+}
+__device__ __forceinline__ bool slab_hit(const float *lo, const float *hi, const SlabRay &s, float tmax, float &tn) {
+    const float ax = __builtin_fmaf(s.sx ? hi[0] : lo[0], s.ix, s.nx), bx = __builtin_fmaf(s.sx ? lo[0] : hi[0], s.ix, s.fx);
+    const float ay = __builtin_fmaf(s.sy ? hi[1] : lo[1], s.iy, s.ny), by = __builtin_fmaf(s.sy ? lo[1] : hi[1], s.iy, s.fy);
+    const float az = __builtin_fmaf(s.sz ? hi[2] : lo[2], s.iz, s.nz), bz = __builtin_fmaf(s.sz ? lo[2] : hi[2], s.iz, s.fz);
+    tn = fmaxf(fmaxf(ax, ay), fmaxf(az, 0.0f));
+    const float tf = fminf(fminf(bx, by), fminf(bz, tmax));
+    return tn <= tf;
+}
+
 template <int CTRL> __device__ __forceinline__ uint32_t min_dpp(uint32_t v) {
     const uint32_t o = dpp<CTRL>(v);
     return o < v ? o : v;
@@ -381,7 +407,7 @@ __device__ __forceinline__ void mesh_closest(const SceneView &sv, const rthip_me
     const char *nodes = reinterpret_cast<const char *>(sv.bvh_nodes + m.bvh_node_base) + (q << 5);
     const rthip_tri *tris = sv.bvh_tris + m.bvh_tri_base;
     const uint32_t *index = sv.bvh_tri_index + m.bvh_tri_base;
-    const BvhRay r = bvh_ray(o, d, m.abs_max);
+    const SlabRay r = slab_ray(bvh_ray(o, d, m.abs_max));
     const uint32_t kSkip = 0x7ffffffeu;              // "pop again": no leaf bit, never a node index
     const uint32_t kDone = RTHIP_BVH_ABSENT;         // has the leaf bit: leaves the interior loop
     const uint32_t kNone = 0xfffffffcu;
@@ -408,9 +434,7 @@ __device__ __forceinline__ void mesh_closest(const SceneView &sv, const rthip_me
             const float hi[3] = {__uint_as_float(A.w), __uint_as_float(B.x), __uint_as_float(B.y)};
             const uint32_t child = B.z;
             float tn;
-            bool h;
-            bvh_slab(lo, hi, r, tmax, tn, h);
-            h = h && valid && child != RTHIP_BVH_ABSENT;
+            const bool h = slab_hit(lo, hi, r, tmax, tn) && valid && child != RTHIP_BVH_ABSENT;
             const uint32_t key = h ? ((__float_as_uint(tn) & ~3u) | q) : (kNone | q);  // tn >= 0: bit order == value order
             uint32_t kmin = min_dpp<kXor1>(key);
             kmin = min_dpp<kXor2>(kmin);
@@ -548,13 +572,16 @@ __device__ __forceinline__ int32_t cast_ray(const SceneView &sv, V3 o, V3 d, Sta
 
 // rtc::trace_stage for the quad's ray
 template <bool COUNT>
+// The hit record is stored as soon as the closest query is resolved (mask 0), so that the local point and the
+// normal do not stay in registers through the shadow walks; the caller patches the shadow mask in afterwards.
 __device__ __forceinline__ bool trace_stage(const SceneView &sv, V3 o, V3 d, uint32_t n_shadow_lights, Stack qs, uint32_t q,
-                                            bool live, HitRec &h, KdCounters &cnt) {
+                                            bool live, const Work &w, uint32_t i, int32_t &out_shape, int32_t &out_tri,
+                                            uint32_t &out_mask, KdCounters &cnt) {
     bool redo = false;
-    h.shape = -1;
-    h.tri = -1;
-    h.shadow_mask = 0;
-    h.local = h.normal = mk(0, 0, 0);
+    struct {
+        int32_t shape, tri;
+        uint32_t shadow_mask;
+    } h = {-1, -1, 0u};
     V3 point = mk(0, 0, 0);
     for (int32_t l = -1; l < (int32_t)n_shadow_lights; l++) {
         V3 ro = o, rd = d;
@@ -578,14 +605,24 @@ __device__ __forceinline__ bool trace_stage(const SceneView &sv, V3 o, V3 d, uin
                 hit_details(sv, o, d, shape, tri, c, (COUNT && q == 0) ? &cnt : nullptr);
                 h.shape = shape;
                 h.tri = tri;
-                h.local = c.local;
-                h.normal = c.normal;
                 point = c.point;
+                if (q == 0) {
+                    HitRec rec;
+                    rec.shape = shape;
+                    rec.tri = tri;
+                    rec.shadow_mask = 0;
+                    rec.local = c.local;
+                    rec.normal = c.normal;
+                    store_hit(w, i, rec);
+                }
             }
         } else if (shape >= 0) {
             h.shadow_mask |= 1u << l;
         }
     }
+    out_shape = h.shape;
+    out_tri = h.tri;
+    out_mask = h.shadow_mask;
     return !redo;
 }
 }  // namespace quad
@@ -878,18 +915,28 @@ __global__ __launch_bounds__(kBlock, RT_QUAD_OCC) void k_trace_quad(SceneView sv
             o = mk(r.ox, r.oy, r.oz);
             d = mk(r.dx, r.dy, r.dz);
         }
-        HitRec h;
-        const bool done = quad::trace_stage<COUNT>(sv, o, d, n_shadow, qs, q, live, h, kc);
+        int32_t hit_shape, hit_tri;
+        uint32_t shadow_mask;
+        const bool done = quad::trace_stage<COUNT>(sv, o, d, n_shadow, qs, q, live, w, i, hit_shape, hit_tri, shadow_mask, kc);
         if (!live || q != 0) continue;
         if (COUNT && kc.nodes - nodes_before > max_ray_nodes) max_ray_nodes = kc.nodes - nodes_before;
         if (!done) {
             w.redo[atomicAdd(&w.redo_count[0], 1u)] = i;
             continue;
         }
-        store_hit(w, i, h);
+        if (hit_shape < 0) {  // a miss: the whole record
+            HitRec h;
+            h.shape = -1;
+            h.tri = -1;
+            h.shadow_mask = 0;
+            h.local = h.normal = mk(0, 0, 0);
+            store_hit(w, i, h);
+        } else if (shadow_mask) {
+            w.hit[i].mask = shadow_mask;  // the record itself was stored after the closest query
+        }
         if (level == 0 && w.id_shape && i / fp.n_pix_slots == (fp.aa ? 4u : 0u)) {
-            w.id_shape[pix_slot] = h.shape;
-            w.id_tri[pix_slot] = h.tri;
+            w.id_shape[pix_slot] = hit_shape;
+            w.id_tri[pix_slot] = hit_tri;
         }
     }
     if (COUNT) trace_counters_flush(fp, w, kc, max_ray_nodes, t_start);
