@@ -77,7 +77,8 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--inflight", type=int, default=3, help="frames in flight (one context + HIP stream each)")
+    ap.add_argument("--inflight", type=int, default=0, help="frames in flight (one context + HIP stream each); 0 = 3 on one GPU, 4 on several "
+                    "(a rank's share of a frame is small: more of its latency-bound kernel chain has to overlap)")
     ap.add_argument("--force-gather", action="store_true", help="run the RCCL gather + assemble path even with one rank")
     args = ap.parse_args()
 
@@ -123,7 +124,7 @@ def main():
     # Timed contexts: `inflight` frames are in flight at once, each on its own context (own HIP stream, own
     # workspace, own output buffers), so that the latency-bound tail of one frame's kernels overlaps with the
     # next frame's work.  Every frame is traced completely; frame k uses context k % inflight.
-    F = max(1, args.inflight)
+    F = args.inflight if args.inflight > 0 else (3 if world == 1 else 4)
     ctxs, mines, gathers, frames, exts = [], [], [], [], []
     for k in range(F):
         c = device.Context(local_rank)
