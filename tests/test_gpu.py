@@ -186,6 +186,30 @@ def test_multi_mesh_scene_matches_oracle(oracle_lib):
         assert (got["tri"] >= 0).mean() > 0.2          # the meshes fill a good part of the view
 
 
+def test_graph_replay_gives_the_same_frames_as_plain_launches(monkeypatch):
+    """the frame's launch sequence is captured into a HIP graph and replayed; a changed camera / size / recursion
+    depth re-captures.  Same pixels and ray counts as with RTHIP_GRAPH=0."""
+    sd = scenes.config(3, cam_z=2.5)[0]
+    hs = host.HostScene(sd)
+    desc = hs.flatten()
+    plans = [(256, 144, 3), (256, 144, 3), (256, 144, 1), (192, 108, 3), (256, 144, 3)]
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("RTHIP_GRAPH", mode)
+        c = device.Context(0)
+        c.upload(desc)
+        res = []
+        for k, (w, h, mr) in enumerate(plans):
+            r = c.render(hs.camera(w, h), device.make_params(w, h, mr))
+            st = c.stats()
+            res.append((r["pixels"].copy(), st.rays_primary + st.rays_shadow + st.rays_reflect))
+        c.close()
+        out[mode] = res
+    for a, b in zip(out["1"], out["0"]):
+        assert np.array_equal(a[0], b[0]) and a[1] == b[1] and a[1] > 0
+    assert np.array_equal(out["1"][0][0], out["1"][1][0]) and np.array_equal(out["1"][0][0], out["1"][4][0])
+
+
 def test_chunked_frames_are_identical(monkeypatch):
     """frames larger than the per-level workspace are rendered chunk by chunk (8K x SSAA in production); forcing a
     tiny chunk must not change a pixel or a ray count"""
