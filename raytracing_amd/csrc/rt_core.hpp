@@ -732,36 +732,22 @@ struct Hit {
     V3 point, local, normal;
 };
 
-// Shape::Intersect of one shape in its local frame: hit flag, local hit point, winning triangle
-// FAST = true: meshes go through the BVH only; a degenerate (ray, mesh) pair (kd_degenerate_ray) or a
-// BVH stack overflow is not resolved here but reported through `redo`, and the caller re-runs the whole
-// ray with FAST = false, whose instantiation also contains the reference kd-tree walk and a full-depth
-// stack.  Keeping those rare paths out of the hot kernel keeps its register footprint and code size down.
-// t_stop: see mesh_closest_bvh (3e38f for a closest-hit query).
-template <bool FAST, bool COUNT>
+// Shape::Intersect of one shape in its local frame: hit flag, local hit point, winning triangle.
+// One ray per lane (probes, the redo kernel, accel = 1, the CPU test build): meshes go through the 4-wide BVH
+// unless the ray is one only the reference's kd-tree reproduces (kd_degenerate_ray) or accel = 1 asks for the
+// kd-tree everywhere.  t_stop: see mesh_closest_bvh (3e38f for a closest-hit query).
+template <bool COUNT>
 RT_HD bool shape_intersect(const SceneView &sv, int32_t type, int32_t mesh, V3 plane_n, V3 lo, V3 ld, KdStack &st, float t_stop,
-                           V3 &p, int32_t &tri, bool &redo, KdCounters *cnt) {
+                           V3 &p, int32_t &tri, KdCounters *cnt) {
     tri = -1;
     if (type == RTHIP_SHAPE_SPHERE) return sphere_intersect(lo, ld, p);
     if (type == RTHIP_SHAPE_PLANE) return plane_intersect(plane_n, lo, ld, p);
     const rthip_mesh m = rt_load_mesh(sv.meshes + mesh);  // `mesh` is wave-uniform: scalar loads
     TriBest tb;
-    if (FAST) {
-        if (kd_degenerate_ray(sv, m, lo, ld)) {
-            redo = true;
-            return false;
-        }
+    if (sv.accel == 0 && !kd_degenerate_ray(sv, m, lo, ld))
         mesh_closest_bvh<COUNT>(sv, m, lo, ld, st, tb, t_stop, cnt);
-        if (st.overflow) {
-            redo = true;
-            return false;
-        }
-    } else {
-        if (sv.accel == 0 && !kd_degenerate_ray(sv, m, lo, ld))
-            mesh_closest_bvh<COUNT>(sv, m, lo, ld, st, tb, t_stop, cnt);
-        else
-            mesh_closest(sv, m, lo, ld, st, tb, cnt);
-    }
+    else
+        mesh_closest(sv, m, lo, ld, st, tb, cnt);
     if (!tb.hit) return false;
     tri = (int32_t)tb.tri;
     double u, v, w;
@@ -820,9 +806,9 @@ RT_HD float anyhit_t_stop(const double *fwd, double rt_lin, double rt_t, V3 o, V
 // (CastShadowRay only consumes .Hit, Raytracer.cpp:305-310).  `active` = false makes the call a
 // no-op for this lane: the shape loop runs a wave-uniform number of times so that the shape records
 // are fetched with scalar loads.
-template <bool FAST, bool COUNT>
+template <bool COUNT>
 RT_HD int32_t cast_ray_id(const SceneView &sv, V3 o, V3 d, KdStack &st, bool any_hit, bool active, int32_t &best_tri,
-                          bool &redo, KdCounters *cnt) {
+                          KdCounters *cnt) {
     int32_t best = -1;
     best_tri = -1;
     double hitDistance = DBL_MAX;
@@ -843,8 +829,8 @@ RT_HD int32_t cast_ray_id(const SceneView &sv, V3 o, V3 d, KdStack &st, bool any
         int32_t tri;
         float t_stop = 3.0e38f;
         if (any_hit && type == RTHIP_SHAPE_MESH) t_stop = anyhit_t_stop(fwd, sh->rt_lin, sh->rt_t, o, ld);
-        if (!shape_intersect<FAST, COUNT>(sv, type, sh->mesh, mk(sh->plane_n[0], sh->plane_n[1], sh->plane_n[2]), lo, ld, st,
-                                          t_stop, p, tri, redo, cnt))
+        if (!shape_intersect<COUNT>(sv, type, sh->mesh, mk(sh->plane_n[0], sh->plane_n[1], sh->plane_n[2]), lo, ld, st, t_stop, p,
+                                    tri, cnt))
             continue;
         V3 worldPoint = xform(fwd, p, 1.0);
         double distance = sqlen(sub(o, worldPoint));
@@ -894,11 +880,10 @@ RT_HD void hit_details(const SceneView &sv, V3 o, V3 d, int32_t shape, int32_t t
 RT_HD Hit cast_ray(const SceneView &sv, V3 o, V3 d, KdStack &st, bool any_hit, KdCounters *cnt) {
     Hit h;
     h.point = h.local = h.normal = mk(0, 0, 0);
-    bool redo = false;
     if (cnt)
-        h.shape = cast_ray_id<false, true>(sv, o, d, st, any_hit, true, h.tri, redo, cnt);
+        h.shape = cast_ray_id<true>(sv, o, d, st, any_hit, true, h.tri, cnt);
     else
-        h.shape = cast_ray_id<false, false>(sv, o, d, st, any_hit, true, h.tri, redo, cnt);
+        h.shape = cast_ray_id<false>(sv, o, d, st, any_hit, true, h.tri, cnt);
     if (h.shape >= 0 && !any_hit) hit_details(sv, o, d, h.shape, h.tri, h, cnt);
     return h;
 }
@@ -919,10 +904,8 @@ struct HitRec {
 // serves both query kinds so the traversal code is instantiated once; the query loop runs a
 // wave-uniform number of times (lanes without a hit idle through the shadow queries).
 // n_shadow_lights = 0 gives the single closest-hit query of the DebugRaycaster (Raytracer.cpp:317-351).
-// Returns false (FAST only) when the ray met a degenerate (ray, mesh) pair and must be re-run with FAST = false.
-template <bool FAST, bool COUNT>
-RT_HD bool trace_stage(const SceneView &sv, V3 o, V3 d, uint32_t n_shadow_lights, KdStack &st, HitRec &h, KdCounters *cnt) {
-    bool redo = false;
+template <bool COUNT>
+RT_HD void trace_stage(const SceneView &sv, V3 o, V3 d, uint32_t n_shadow_lights, KdStack &st, HitRec &h, KdCounters *cnt) {
     h.shape = -1;
     h.tri = -1;
     h.shadow_mask = 0;
@@ -930,7 +913,7 @@ RT_HD bool trace_stage(const SceneView &sv, V3 o, V3 d, uint32_t n_shadow_lights
     V3 point = mk(0, 0, 0);
     for (int32_t q = -1; q < (int32_t)n_shadow_lights; q++) {
         V3 ro = o, rd = d;
-        bool active = !redo;
+        bool active = true;
         if (q >= 0) {
             const rt_uniform_light *light = rt_uniform_cast(sv.lights) + q;
             const int32_t ltype = light->type;
@@ -943,9 +926,9 @@ RT_HD bool trace_stage(const SceneView &sv, V3 o, V3 d, uint32_t n_shadow_lights
                 rd = normalized(sub(mk(light->position[0], light->position[1], light->position[2]), point));
         }
         int32_t tri;
-        int32_t shape = cast_ray_id<FAST, COUNT>(sv, ro, rd, st, q >= 0, active, tri, redo, cnt);
+        int32_t shape = cast_ray_id<COUNT>(sv, ro, rd, st, q >= 0, active, tri, cnt);
         if (q < 0) {
-            if (shape >= 0 && !redo) {
+            if (shape >= 0) {
                 Hit c;
                 hit_details(sv, o, d, shape, tri, c, cnt);
                 h.shape = shape;
@@ -958,7 +941,6 @@ RT_HD bool trace_stage(const SceneView &sv, V3 o, V3 d, uint32_t n_shadow_lights
             h.shadow_mask |= 1u << q;
         }
     }
-    return !(FAST && redo);
 }
 
 struct ShadeOut {
@@ -1032,9 +1014,9 @@ struct Bounce {
 RT_HD void bounce(const SceneView &sv, V3 ro, V3 rd, bool may_reflect, KdStack &st, Bounce &out, KdCounters *cnt) {
     HitRec h;
     if (cnt)
-        trace_stage<false, true>(sv, ro, rd, sv.n_lights, st, h, cnt);
+        trace_stage<true>(sv, ro, rd, sv.n_lights, st, h, cnt);
     else
-        trace_stage<false, false>(sv, ro, rd, sv.n_lights, st, h, cnt);
+        trace_stage<false>(sv, ro, rd, sv.n_lights, st, h, cnt);
     ShadeOut so;
     shade_stage(sv, sv.perlin_tables, h, rd, may_reflect, so);
     out.color = so.color;

@@ -9,11 +9,11 @@
 //                      wave ballot + prefix popcount and ONE atomic per workgroup); the others are listed.
 //   k_trace_quad     : the listed rays, FOUR LANES PER RAY over the 4-wide BVH (namespace quad), exact fp64
 //                      triangle tests; writes hit records.
-//   k_trace<.,true>  : redo list (rays only the reference kd-tree reproduces); normally empty.
+//   k_trace<true,.>  : redo list (rays only the reference kd-tree reproduces); normally empty.
 //   k_shade<true>    : shading + spawn of the listed rays from their hit records.
 // then k_resolve: per pixel, C_k = direct_k (+) C_{k+1} (x) refl_k folded back to front along the pixel's
 // chain of rays (clamping Color algebra forbids a forward throughput product), 3x3 SSAA
-// sum, 0xAABBGGRR pack.  accel = 1 runs k_trace<false,false> + k_shade<false> instead (reference kd-tree,
+// sum, 0xAABBGGRR pack.  accel = 1 runs k_trace<false,.> + k_shade<false> instead (reference kd-tree,
 // one ray per lane).  No MFMA: the path is divergent fp64 VALU work.
 //
 // Built with -ffp-contract=off: the oracle is the non-fused x86-64 build of the reference.
@@ -72,6 +72,9 @@ static const uint32_t kBlock = 256;           // 4 waves per workgroup
 // bound by dependent fp64 chains, so resident waves matter more than a few spilled values)
 #ifndef RT_TRACE_OCC
 #define RT_TRACE_OCC 4
+#endif
+#ifndef RT_EASY_OCC
+#define RT_EASY_OCC 4
 #endif
 #ifndef RT_QUAD_OCC
 #define RT_QUAD_OCC 4
@@ -226,18 +229,15 @@ __device__ __forceinline__ void trace_counters_flush(const FrameParams &fp, cons
         }
 }
 
-// Stage 1 of a level: every scene query of the level.
-// Level 0 generates its rays (R1).  Output: one HitRec per ray (SoA) + the ray direction.
-// FAST = true is the hot instantiation: BVH only; rays that meet a degenerate (ray, mesh) pair are
-// appended to the redo list and re-traced by the FAST = false instantiation (which also serves
-// accel = 1, the reference kd-tree everywhere).  REDO = true: `n` and the ray indices come from the
-// redo list.
-template <bool FAST, bool REDO, bool COUNT>
+// One ray per lane through every scene query of the ray: the whole
+// trace stage of accel = 1 (reference kd-tree everywhere), and with REDO = true the re-trace of the listed rays
+// the quad kernel could not resolve (`n` and the ray indices come from the redo list).  Level 0 generates its
+// rays (R1).  Output: one hit record per ray.
+template <bool REDO, bool COUNT>
 __global__ __launch_bounds__(kBlock, RT_TRACE_OCC) void k_trace(SceneView sv, FrameParams fp, Work w, uint32_t level,
                                                                  uint32_t stack_cap) {
-    // LDS: stack_cap child words per lane, then (FAST only) stack_cap entry parameters per lane
-    KdStack st = make_stack(lds_dyn + threadIdx.x, kBlock, stack_cap,
-                            FAST ? reinterpret_cast<float *>(lds_dyn + (size_t)stack_cap * kBlock) + threadIdx.x : nullptr);
+    // LDS: stack_cap child words per lane (no entry parameters: nothing is culled on a pop here)
+    KdStack st = make_stack(lds_dyn + threadIdx.x, kBlock, stack_cap, nullptr);
     const uint32_t n = REDO ? w.redo_count[0] : ((level == 0) ? fp.N0 : w.counts[level]);
     const uint32_t n_shadow = fp.renderer == RTHIP_RENDER_RAYTRACER ? sv.n_lights : 0u;  // DebugRaycaster: closest hit only
     KdCounters kc = {0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -278,14 +278,9 @@ __global__ __launch_bounds__(kBlock, RT_TRACE_OCC) void k_trace(SceneView sv, Fr
         // ray that is never traced (n_shapes = 0 would need a second code path)
         HitRec h;
         st.overflow = false;
-        bool done = true;
-        if (live) done = trace_stage<FAST, COUNT>(sv, o, d, n_shadow, st, h, COUNT ? &kc : nullptr);
+        if (live) trace_stage<COUNT>(sv, o, d, n_shadow, st, h, COUNT ? &kc : nullptr);
         if (!live) continue;
         if (COUNT && kc.nodes - nodes_before > max_ray_nodes) max_ray_nodes = kc.nodes - nodes_before;
-        if (FAST && !done) {  // rare: hand the ray to the full instantiation
-            w.redo[atomicAdd(&w.redo_count[0], 1u)] = i;
-            continue;
-        }
         store_hit(w, i, h);
         // primary-hit ids come from the un-offset pixel-centre ray (sub-sample 4 of the 3x3 SSAA grid)
         if (level == 0 && w.id_shape && i / fp.n_pix_slots == (fp.aa ? 4u : 0u)) {
@@ -813,7 +808,7 @@ __device__ __forceinline__ bool trace_stage(const SceneView &sv, V3 o, V3 d, uin
 // Also stage 2 for the rays it finishes: they are shaded on the spot (no hit record leaves the
 // registers) and their reflected rays go straight to the next level's queue.
 template <bool COUNT>
-__global__ __launch_bounds__(kBlock, RT_TRACE_OCC) void k_trace_easy(SceneView sv, FrameParams fp, Work w, uint32_t level,
+__global__ __launch_bounds__(kBlock, RT_EASY_OCC) void k_trace_easy(SceneView sv, FrameParams fp, Work w, uint32_t level,
                                                                       uint32_t n_tables, uint32_t levels) {
     __shared__ ShadeShared sh;
     const uint32_t n = (level == 0) ? fp.N0 : w.counts[level];
@@ -878,7 +873,7 @@ __global__ __launch_bounds__(kBlock, RT_TRACE_OCC) void k_trace_easy(SceneView s
 
 // Stage 1b of a level for the BVH path (accel = 0): the rays k_trace_easy listed as needing a mesh walk,
 // four lanes per ray, see namespace quad.  Rays the quad walk cannot finish (degenerate (ray, mesh) pairs,
-// stack overflow) go to the redo list and are re-traced by k_trace<false, true>.
+// stack overflow) go to the redo list and are re-traced by the redo instantiation of k_trace.
 template <bool COUNT>
 __global__ __launch_bounds__(kBlock, RT_QUAD_OCC) void k_trace_quad(SceneView sv, FrameParams fp, Work w, uint32_t level,
                                                                      uint32_t stack_cap) {
@@ -1467,10 +1462,10 @@ static int render_frame(rthip_ctx *c, const rthip_camera *cam, const rthip_param
     const size_t lds_bytes = (size_t)c->stack_cap * kBlock * sizeof(uint32_t);
     if (lds_bytes > 160 * 1024) return fail(RTHIP_E_UNSUPPORTED, "kd stack of %u entries does not fit LDS", c->stack_cap);
     if (lds_bytes > 64 * 1024) {
-        HIP_TRY(hipFuncSetAttribute((const void *)k_trace<false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        HIP_TRY(hipFuncSetAttribute((const void *)k_trace<false, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        HIP_TRY(hipFuncSetAttribute((const void *)k_trace<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        HIP_TRY(hipFuncSetAttribute((const void *)k_trace<false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        HIP_TRY(hipFuncSetAttribute((const void *)k_trace<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        HIP_TRY(hipFuncSetAttribute((const void *)k_trace<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        HIP_TRY(hipFuncSetAttribute((const void *)k_trace<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        HIP_TRY(hipFuncSetAttribute((const void *)k_trace<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     }
     // hot kernel: one short stack per quad (child word + entry parameter per entry); deeper rays overflow into the redo list
     const uint32_t quad_cap = 3 * c->bvh_depth + 1;  // cannot overflow, see quad::Stack
@@ -1552,16 +1547,16 @@ static int render_frame(rthip_ctx *c, const rthip_camera *cam, const rthip_param
                 if (c->profile_launches) HIP_TRY(hipEventRecord(eb, c->stream));
                 if (c->has_meshes) {  // re-trace of the (rare) rays lying exactly in a kd split plane or overflowing the short stack
                     if (c->count_kd)
-                        hipLaunchKernelGGL((k_trace<false, true, true>), dim3(64), dim3(kBlock), lds_bytes, c->stream, c->sv, fp, w, level, c->stack_cap);
+                        hipLaunchKernelGGL((k_trace<true, true>), dim3(64), dim3(kBlock), lds_bytes, c->stream, c->sv, fp, w, level, c->stack_cap);
                     else
-                        hipLaunchKernelGGL((k_trace<false, true, false>), dim3(64), dim3(kBlock), lds_bytes, c->stream, c->sv, fp, w, level, c->stack_cap);
+                        hipLaunchKernelGGL((k_trace<true, false>), dim3(64), dim3(kBlock), lds_bytes, c->stream, c->sv, fp, w, level, c->stack_cap);
                 }
             } else {
                 if (c->profile_launches) HIP_TRY(hipEventRecord(eq, c->stream));
                 if (c->count_kd)
-                    hipLaunchKernelGGL((k_trace<false, false, true>), dim3(grid), dim3(kBlock), lds_bytes, c->stream, c->sv, fp, w, level, c->stack_cap);
+                    hipLaunchKernelGGL((k_trace<false, true>), dim3(grid), dim3(kBlock), lds_bytes, c->stream, c->sv, fp, w, level, c->stack_cap);
                 else
-                    hipLaunchKernelGGL((k_trace<false, false, false>), dim3(grid), dim3(kBlock), lds_bytes, c->stream, c->sv, fp, w, level, c->stack_cap);
+                    hipLaunchKernelGGL((k_trace<false, false>), dim3(grid), dim3(kBlock), lds_bytes, c->stream, c->sv, fp, w, level, c->stack_cap);
                 if (c->profile_launches) HIP_TRY(hipEventRecord(eb, c->stream));
             }
             if (p->accel == 0) {
