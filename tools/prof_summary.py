@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Per-kernel summary of the PMC passes of tools/prof_passes.sh (one directory per pass) as markdown:
+VALU utilisation, wait fractions, L2 hit rate, HBM read traffic, against the kernel's GPU time."""
+import collections, csv, glob, sys
+d, frames = sys.argv[1], int(sys.argv[2])
+acc = collections.defaultdict(lambda: collections.defaultdict(float))
+calls = collections.defaultdict(int)
+for f in glob.glob(d + "/*/**/*counter_collection.csv", recursive=True):
+    seen = set()
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        if r["Counter_Name"] == "SQ_WAVES":
+            calls[k] += 1
+print(f"PMC summary of `{d}` ({frames} frames; rocprofv3 --pmc, one pass per counter group, MI355X)\n")
+print("| kernel | launches/frame | waves/frame | VALU instr/frame (M) | VALU issue util. of the SIMDs | wave time in s_waitcnt | issue-stalled | L2 hit rate | HBM/MALL read MB/frame | GPU ms/frame |")
+print("|---|---|---|---|---|---|---|---|---|---|")
+for k, c in sorted(acc.items()):
+    if not k.startswith("k_") or c.get("SQ_WAVES", 0) == 0:
+        continue
+    wc = c["SQ_WAVE_CYCLES"]
+    # GRBM_GUI_ACTIVE is summed over the 8 XCDs; 2.4 GHz nominal
+    ms = c.get("GRBM_GUI_ACTIVE", 0) / 8 / 2.4e6 / frames
+    simd_cycles = c.get("GRBM_GUI_ACTIVE", 0) / 8 * 1024
+    valu_util = 4.0 * c["SQ_ACTIVE_INST_VALU"] / simd_cycles if simd_cycles else 0
+    req = c.get("TCC_REQ_sum", 0)
+    print(f"| `{k}` | {calls[k] / frames:.0f} | {c['SQ_WAVES'] / frames:,.0f} | {c['SQ_INSTS_VALU'] / frames / 1e6:.1f} | {100 * valu_util:.0f} % | "
+          f"{100 * c['SQ_WAIT_ANY'] / wc:.0f} % | {100 * c['SQ_WAIT_INST_ANY'] / wc:.0f} % | {100 * c.get('TCC_HIT_sum', 0) / req if req else 0:.0f} % | "
+          f"{c.get('TCC_EA0_RDREQ_sum', 0) * 128 / frames / 1e6:.1f} | {ms:.3f} |")
+print("\nVALU issue utilisation = 4 cycles x SQ_ACTIVE_INST_VALU / (1024 SIMDs x kernel cycles); HBM/MALL read = TCC_EA0_RDREQ x 128 B "
+      "(gfx950 tallies 128-byte requests, MI355X_MICROARCH.md); GPU ms from GRBM_GUI_ACTIVE at 2.4 GHz (PMC runs serialise kernels).")
