@@ -9,6 +9,13 @@ region; every step traces the whole frame.  With N > 1 the frame is partitioned 
 HBM, the buffers are all-gathered over RCCL and assembled into the frame on the device; total work
 is fixed as N grows ("strong" scaling).
 
+Frames are traced in runs: one rthip_render_batch_device call takes --batch frames (default 8; the same camera for
+all of them here, but every frame is traced in full — nothing is reused between frames) through ONE set of kernel
+launches, and --inflight calls (default 3) are in flight on separate HIP streams.  A run of frames is what a camera
+path rendered ahead of time looks like; it is also what keeps a GPU busy when its share of a 1080p frame is an
+eighth of it (a frame is ~20 dependent launches, each of them latency-bound on so few rays).  --steps K times exactly
+K frames: K // batch full calls and one shorter call.  --latency also reports the latency of a single frame.
+
 Prints ONE JSON line (rank 0).  Extra objects: "roofline" (dominant kernel k_trace_quad, algorithmic
 bytes from SURVEY.md §8d's per-ray formula with counts measured on this frame) and "cpu_baseline"
 (the genuine reference compiled in oracle/_ref — or the C oracle port — timed on the host cores).
@@ -79,6 +86,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--inflight", type=int, default=0, help="frames in flight (one context + HIP stream each); 0 = 3 on one GPU, 4 on several "
                     "(a rank's share of a frame is small: more of its latency-bound kernel chain has to overlap)")
+    ap.add_argument("--batch", type=int, default=0, help="frames traced per call (rthip_render_batch_device: one set of launches for "
+                    "the rays of all of them); 0 = 8, the library's limit")
+    ap.add_argument("--latency", action="store_true", help="also measure the latency of ONE frame with nothing else in flight "
+                    "(off by default so that every k_trace_quad launch of a default run has the same size: the rocprofv3 --stats "
+                    "average of the same command is then comparable with roofline.avg_launch_ms)")
     ap.add_argument("--force-gather", action="store_true", help="run the RCCL gather + assemble path even with one rank")
     args = ap.parse_args()
 
@@ -107,49 +119,68 @@ def main():
     gather = world > 1 or args.force_gather
     prm = device.make_params(W, H, MAX_REC, part_index=rank, part_count=world, layout=1 if gather else 0)
 
-    # one untimed frame on a counting context: per-frame ray and kd-traversal counts (this rank's share)
+    part_px = device.part_pixels(prm)
+    B = args.batch if args.batch > 0 else device.MAX_BATCH
+    if B > device.MAX_BATCH:
+        raise SystemExit(f"--batch {B} > {device.MAX_BATCH}")
+    cam_runs = {n: (device.Camera * n)(*([cam] * n)) for n in range(1, B + 1)}
+
+    # one untimed call on a counting context: ray and BVH-traversal counts of one call of B frames (this rank's share)
     os.environ["RTHIP_COUNTERS"] = "1"
     cctx = device.Context(local_rank)
     os.environ["RTHIP_COUNTERS"] = "0"
     cctx.upload(desc)
-    part_px = device.part_pixels(prm)
-    frame = torch.zeros(W * H, dtype=torch.int32, device="cuda")
-    mine = torch.zeros(part_px, dtype=torch.int32, device="cuda") if gather else frame
-    cctx.render_device(cam, prm, mine.data_ptr(), sync=True)
+    scratch = torch.zeros(B * (part_px if gather else W * H), dtype=torch.int32, device="cuda")
+    cctx.render_batch_device(cam_runs[B], prm, scratch.data_ptr(), sync=True)
     cst = cctx.stats()
-    abytes = algorithmic_bytes(cst)
-    my_rays = cst.rays_primary + cst.rays_shadow + cst.rays_reflect
+    abytes = algorithmic_bytes(cst)  # per call
+    my_rays = (cst.rays_primary + cst.rays_shadow + cst.rays_reflect) // B  # per frame
     cctx.close()
+    del scratch
 
     # Timed contexts: `inflight` frames are in flight at once, each on its own context (own HIP stream, own
     # workspace, own output buffers), so that the latency-bound tail of one frame's kernels overlaps with the
     # next frame's work.  Every frame is traced completely; frame k uses context k % inflight.
-    F = args.inflight if args.inflight > 0 else (3 if world == 1 else 4)
+    # A call traces a run of B frames (one camera each; here the same camera B times, every frame traced in full) as
+    # one set of launches: the ~20 dependent launches of a frame then work on B frames' rays, which is what keeps a
+    # GPU busy when its share of a 1080p frame is an eighth of it.  One RCCL all-gather per call.
+    F = args.inflight if args.inflight > 0 else 3
     ctxs, mines, gathers, frames, exts = [], [], [], [], []
     for k in range(F):
         c = device.Context(local_rank)
         c.upload(desc)
         ctxs.append(c)
-        fr = frame if k == 0 else torch.zeros(W * H, dtype=torch.int32, device="cuda")
+        fr = torch.zeros(B * W * H, dtype=torch.int32, device="cuda")
         frames.append(fr)
-        mines.append(torch.zeros(part_px, dtype=torch.int32, device="cuda") if gather else fr)
-        gathers.append(torch.zeros(part_px * world, dtype=torch.int32, device="cuda") if gather else None)
+        mines.append(torch.zeros(B * part_px, dtype=torch.int32, device="cuda") if gather else fr)
+        gathers.append(torch.zeros(B * part_px * world, dtype=torch.int32, device="cuda") if gather else None)
         exts.append(torch.cuda.ExternalStream(c.stream()))
     comm = torch.cuda.current_stream()
 
-    def step(k):
+    def call(k, n):
+        """call k: the next n (<= B) frames, on context k % F"""
         j = k % F
         c = ctxs[j]
-        c.render_device(cam, prm, mines[j].data_ptr(), sync=False)
+        c.render_batch_device(cam_runs[n], prm, mines[j].data_ptr(), sync=False)
         if gather:  # device-side ordering only: render -> RCCL all-gather (torch's stream) -> assemble (context's stream)
             done = torch.cuda.Event()
             done.record(exts[j])
             comm.wait_event(done)
-            dist.all_gather_into_tensor(gathers[j], mines[j])
+            mine, gath = mines[j][:n * part_px], gathers[j][:n * part_px * world]
+            dist.all_gather_into_tensor(gath, mine)
             gathered_ev = torch.cuda.Event()
             gathered_ev.record(comm)
             exts[j].wait_event(gathered_ev)
-            c.assemble(prm, gathers[j].data_ptr(), frames[j].data_ptr(), sync=False)
+            c.assemble_batch(prm, n, gath.data_ptr(), frames[j].data_ptr(), sync=False)
+
+    def run_frames(n_frames):
+        """exactly n_frames frames: calls of B, then one shorter call for the remainder"""
+        k = 0
+        while n_frames > 0:
+            n = min(B, n_frames)
+            call(k, n)
+            k += 1
+            n_frames -= n
 
     def sync_all():
         for c in ctxs:
@@ -159,21 +190,22 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for k in range(args.warmup):
-        step(k)
+    run_frames(max(args.warmup, F * B))  # (at least one call per context: workspaces allocated, graphs captured)
+    if args.steps % B:
+        for j in range(F):
+            call(j, args.steps % B)  # the shorter last call has its own captured graph on whichever context gets it
     sync_all()
     t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(k)
+    run_frames(args.steps)
     sync_all()
     dt = time.perf_counter() - t0
 
     # latency of ONE frame (nothing else in flight), and the per-launch duration of the dominant kernel
     # (HIP events on the context's own stream) on a profiling context
     lat = []
-    for _ in range(10):
+    for _ in range(10 if args.latency else 0):
         t1 = time.perf_counter()
-        step(0)
+        call(0, 1)
         sync_all()
         lat.append((time.perf_counter() - t1) * 1e3)
     lat.sort()
@@ -184,7 +216,7 @@ def main():
     os.environ["RTHIP_PROFILE_LAUNCHES"] = "0"
     pctx.upload(desc)
     for _ in range(3):
-        pctx.render_device(cam, prm, mines[0].data_ptr(), sync=True)
+        pctx.render_batch_device(cam_runs[B], prm, mines[0].data_ptr(), sync=True)
     st = pctx.stats()
     pctx.close()
     launch_ms = st.ms_trace / max(1, st.launches_trace)
@@ -195,7 +227,7 @@ def main():
         rays_frame, dt = float(rays_t.item()), float(dt_t.item())
     else:
         rays_frame = float(my_rays)
-    checksum = int(frames[0].to(torch.int64).sum().item()) if rank == 0 else 0
+    checksum = int(frames[0][:W * H].to(torch.int64).sum().item()) if rank == 0 else 0
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
@@ -208,12 +240,13 @@ def main():
             "config": {"workload": "BASELINE configs[2]: Demo 4 bunny.obj (4968 tris, kd-tree) + checker plane + SkyBox sun, "
                                    "1920x1080, MaxRecursion 3, camera (0,0,5)", "rays_per_frame": int(rays_frame),
                        "partition": f"interleaved 32x8 screen tiles over {world} GPU(s)" + (", RCCL all-gather + device assemble" if gather else ""),
-                       "frames_in_flight": F, "single_frame_latency_ms": lat[len(lat) // 2],
+                       "frames_per_call": B, "calls_in_flight": F, "single_frame_latency_ms": lat[len(lat) // 2] if lat else None,
                        "frame_checksum": checksum},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(st.launches_trace),
-                         "kernel": "k_trace_quad", "launches_per_frame": int(st.launches_trace), "avg_launch_ms": launch_ms,
-                         "algorithmic_bytes_per_frame_rank0": int(abytes), "rays_traced_by_kernel_per_frame_rank0": int(cst.rays_hard),
+                         "kernel": "k_trace_quad", "launches_per_call": int(st.launches_trace), "avg_launch_ms": launch_ms,
+                         "algorithmic_bytes_per_call_rank0": int(abytes), "rays_traced_by_kernel_per_call_rank0": int(cst.rays_hard),
+                         "frames_per_call": B,
                          "note": "the flattened bunny BVH (~0.8 MB) is L2-resident: the kernel is bound by the dependent-step "
                                  "latency of its slowest wave, not by HBM; see DESIGN.md"},
         }

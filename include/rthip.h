@@ -108,6 +108,7 @@ typedef struct {
 #define RTHIP_BVH_COUNT_SHIFT 28
 #define RTHIP_BVH_FIRST_MASK 0x0fffffffu
 #define RTHIP_BVH_MAX_LEAF 4
+#define RTHIP_MAX_BATCH 8 /* frames per rthip_render_batch_device call */
 #define RTHIP_BVH_MAX_DEPTH 48
 
 typedef struct {
@@ -282,6 +283,14 @@ int rthip_render(rthip_ctx *ctx, const rthip_camera *cam, const rthip_params *pa
  * context's stream unless `sync` is non-zero.  Used by bench.py and the multi-GPU gather. */
 int rthip_render_device(rthip_ctx *ctx, const rthip_camera *cam, const rthip_params *params,
                         void *d_pixels, int sync);
+/* A run of frames in one call: n_frames (1..RTHIP_MAX_BATCH) cameras over the same scene and params, traced as one
+ * set of launches (the rays of all the frames share the ray queues, so the fixed cost of a frame's ~20 dependent
+ * launches is paid once per call).  d_pixels: n_frames buffers one after the other, each width*height (layout 0) or
+ * rthip_part_pixels() (layout 1) uint32.  Every frame is bit-identical to what rthip_render_device gives for its
+ * camera.  replaces: the frame-after-frame RenderSync loop of the preview (Sandbox/Sandbox.cpp:359), whose camera
+ * path is known ahead; also what keeps a GPU busy when its share of a frame is small (part_count > 1). */
+int rthip_render_batch_device(rthip_ctx *ctx, const rthip_camera *cams, uint32_t n_frames, const rthip_params *params,
+                              void *d_pixels, int sync);
 /* number of uint32 entries of one part's tile-compact buffer (identical for every part_index:
  * ceil(n_tiles / part_count) * tile_w * tile_h), 0 on bad params */
 uint64_t rthip_part_pixels(const rthip_params *params);
@@ -289,6 +298,10 @@ uint64_t rthip_part_pixels(const rthip_params *params);
  * part_count tile-compact buffers of rthip_part_pixels() entries each, part after part (the result
  * of an all-gather / gather over RCCL); writes the width*height row-major frame to d_frame. */
 int rthip_assemble(rthip_ctx *ctx, const rthip_params *params, const void *d_gathered, void *d_frame, int sync);
+/* rthip_assemble for the output of rthip_render_batch_device gathered over the ranks: d_gathered holds, part after
+ * part, n_frames tile-compact buffers each; d_frames receives n_frames row-major frames one after the other. */
+int rthip_assemble_batch(rthip_ctx *ctx, const rthip_params *params, uint32_t n_frames, const void *d_gathered, void *d_frames,
+                         int sync);
 /* HIP stream the context launches on (hipStream_t as void*), so callers can order work after it */
 void *rthip_stream(rthip_ctx *ctx);
 int rthip_synchronize(rthip_ctx *ctx);

@@ -89,11 +89,14 @@ enum { ST_KD_NODES = 0, ST_KD_TRIS, ST_KD_LEAVES, ST_KD_POPS, ST_SHAPES, ST_MESH
 
 // Per-frame constants
 struct FrameParams {
-    rthip_camera cam;
+    rthip_camera cams[RTHIP_MAX_BATCH];  // one per frame of the batch (a plain frame is a batch of one)
+    uint32_t n_frames;
+    uint32_t my_tiles;     // tiles of this part in ONE frame: per-part tile ordinal q = frame * my_tiles + tile
+    uint32_t part_slots;   // pixel slots of one frame's tile-compact part buffer (rthip_part_pixels)
     uint32_t W, H, max_rec;
     int32_t aa, renderer;
     uint32_t part_index, part_count, tile_w, tile_h, tiles_x, tiles_y;
-    uint32_t q0;           // first per-part tile ordinal of this chunk
+    uint32_t q0;           // first per-part tile ordinal (over the whole batch) of this chunk
     uint32_t n_pix_slots;  // tile slots in this chunk * tile_w * tile_h
     uint32_t N0;           // level-0 rays of this chunk = n_pix_slots * (aa ? 9 : 1)
     uint32_t count_kd;     // collect kd counters
@@ -163,18 +166,43 @@ __device__ __forceinline__ void store_no_ray(const Work &w, uint32_t i) {
 // slot (within chunk) -> pixel.  Tiles are tile_w x tile_h; inside a tile the pixels are ordered
 // as 8x8 sub-blocks, and inside a sub-block as four 4x4 patches: 16 consecutive slots (the rays of one
 // wave of the quad trace kernel) cover a compact 4x4 patch, 64 (one shade wave) an 8x8 one.
-__device__ __forceinline__ bool slot_to_pixel(const FrameParams &fp, uint32_t pix_slot, uint32_t &x, uint32_t &y) {
+// `frame` = index within the batch, `part_slot` = slot within that frame's part (tile-compact order).
+__device__ __forceinline__ bool slot_to_pixel(const FrameParams &fp, uint32_t pix_slot, uint32_t &x, uint32_t &y, uint32_t &frame,
+                                              uint32_t &part_slot) {
     uint32_t per_tile = fp.tile_w * fp.tile_h;
     uint32_t q = fp.q0 + pix_slot / per_tile;
     uint32_t r = pix_slot % per_tile;
+    frame = q / fp.my_tiles;
+    q -= frame * fp.my_tiles;
+    part_slot = q * per_tile + r;
     uint32_t t = fp.part_index + q * fp.part_count;
-    if (t >= fp.tiles_x * fp.tiles_y) return false;
+    if (t >= fp.tiles_x * fp.tiles_y || frame >= fp.n_frames) return false;
     uint32_t tx = t % fp.tiles_x, ty = t / fp.tiles_x;
     uint32_t sb = r >> 6, l = r & 63u;
     uint32_t sbx = fp.tile_w >> 3;
     x = tx * fp.tile_w + (sb % sbx) * 8 + ((l & 3u) | ((l >> 2) & 4u));
     y = ty * fp.tile_h + (sb / sbx) * 8 + (((l >> 2) & 3u) | ((l >> 3) & 4u));
     return x < fp.W && y < fp.H;
+}
+
+// Level-0 ray of queue slot i (R1, Raytracer.cpp:102-121; SSAA offsets :134-138: dx outer, dy inner, +-0.5f).
+// False when the slot lies outside the image.  The 64 slots of a wave lie in one tile, hence in one frame of the
+// batch: the camera is read with scalar loads (lane 0 is live whenever any lane of the wave is).
+__device__ __forceinline__ bool primary_ray(const FrameParams &fp, uint32_t i, bool live, uint32_t &pix_slot, V3 &o, V3 &d) {
+    uint32_t s = i / fp.n_pix_slots;  // SSAA sub-sample (0 when aa is off)
+    pix_slot = i - s * fp.n_pix_slots;
+    uint32_t x = 0, y = 0, frame = 0, part_slot = 0;
+    const bool inside = slot_to_pixel(fp, pix_slot, x, y, frame, part_slot);
+    double fx = (double)x, fy = (double)y;
+    if (fp.aa) {
+        int dx = (int)(s / 3) - 1, dy = (int)(s % 3) - 1;
+        fx = (double)((float)x + (float)dx * .5f);
+        fy = (double)((float)(int)y + (float)dy * .5f);
+    }
+    frame = (uint32_t)__builtin_amdgcn_readfirstlane((int)frame);
+    if (frame >= fp.n_frames) frame = 0;
+    screen_ray(fp.cams[frame], fp.W, fp.H, fx, fy, o, d);
+    return live && inside;
 }
 
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
@@ -251,25 +279,14 @@ __global__ __launch_bounds__(kBlock, RT_TRACE_OCC) void k_trace(SceneView sv, Fr
         V3 o = mk(0, 0, 0), d = mk(0, 0, 1);
         uint32_t pix_slot = 0;
         bool live = in_range;
-        if (level == 0) {
-            uint32_t s = i / fp.n_pix_slots;  // SSAA sub-sample (0 when aa is off)
-            pix_slot = i - s * fp.n_pix_slots;
-            uint32_t x = 0, y = 0;
-            if (live && !slot_to_pixel(fp, pix_slot, x, y)) {
-                store_no_ray(w, i);  // slot outside the image
+        if (level == 0) pix_slot = i % fp.n_pix_slots;
+        if (level == 0 && !REDO) {
+            if (!primary_ray(fp, i, live, pix_slot, o, d)) {
+                if (live) store_no_ray(w, i);  // slot outside the image
                 live = false;
             }
-            double fx = (double)x, fy = (double)y;
-            if (fp.aa) {  // Raytracer.cpp:134-138: dx outer, dy inner, offsets +-0.5
-                int dx = (int)(s / 3) - 1, dy = (int)(s % 3) - 1;
-                fx = (double)((float)x + (float)dx * .5f);
-                fy = (double)((float)(int)y + (float)dy * .5f);
-            }
-            screen_ray(fp.cam, fp.W, fp.H, fx, fy, o, d);
-            if (!REDO && live) {
-                store_ray(w, 0, i, o, d, 0u);  // the shade stage needs the direction (background, reflection)
-            }
-        } else if (live) {
+            if (live) store_ray(w, 0, i, o, d, 0u);  // the shade stage needs the direction (background, reflection)
+        } else if (live) {  // (the redo list of level 0 holds rays k_trace_easy has stored)
             const RayRec r = ray_at(w, level, i);
             o = mk(r.ox, r.oy, r.oz);
             d = mk(r.dx, r.dy, r.dz);
@@ -827,17 +844,7 @@ __global__ __launch_bounds__(kBlock, RT_EASY_OCC) void k_trace_easy(SceneView sv
         V3 o = mk(0, 0, 0), d = mk(0, 0, 1);
         uint32_t pix_slot = 0;
         if (level == 0) {
-            uint32_t s = i / fp.n_pix_slots;  // SSAA sub-sample (0 when aa is off)
-            pix_slot = i - s * fp.n_pix_slots;
-            uint32_t x = 0, y = 0;
-            if (live && !slot_to_pixel(fp, pix_slot, x, y)) live = false;  // slot outside the image: k_resolve skips it too
-            double fx = (double)x, fy = (double)y;
-            if (fp.aa) {  // Raytracer.cpp:134-138: dx outer, dy inner, offsets +-0.5
-                int dx = (int)(s / 3) - 1, dy = (int)(s % 3) - 1;
-                fx = (double)((float)x + (float)dx * .5f);
-                fy = (double)((float)(int)y + (float)dy * .5f);
-            }
-            screen_ray(fp.cam, fp.W, fp.H, fx, fy, o, d);
+            live = primary_ray(fp, i, live, pix_slot, o, d);  // a slot outside the image: k_resolve skips it too
         } else if (live) {
             const RayRec r = ray_at(w, level, i);
             o = mk(r.ox, r.oy, r.oz);
@@ -893,19 +900,8 @@ __global__ __launch_bounds__(kBlock, RT_QUAD_OCC) void k_trace_quad(SceneView sv
         const uint32_t nodes_before = kc.nodes;
         V3 o = mk(0, 0, 0), d = mk(0, 0, 1);
         uint32_t pix_slot = 0;
-        if (level == 0) {
-            uint32_t s = i / fp.n_pix_slots;  // SSAA sub-sample (0 when aa is off)
-            pix_slot = i - s * fp.n_pix_slots;
-            uint32_t x = 0, y = 0;
-            if (live) slot_to_pixel(fp, pix_slot, x, y);  // inside the image: the easy kernel listed it
-            double fx = (double)x, fy = (double)y;
-            if (fp.aa) {  // Raytracer.cpp:134-138: dx outer, dy inner, offsets +-0.5
-                int dx = (int)(s / 3) - 1, dy = (int)(s % 3) - 1;
-                fx = (double)((float)x + (float)dx * .5f);
-                fy = (double)((float)(int)y + (float)dy * .5f);
-            }
-            screen_ray(fp.cam, fp.W, fp.H, fx, fy, o, d);  // bit-identical to the easy kernel's ray, whose direction is already stored
-        } else if (live) {
+        if (level == 0) pix_slot = i % fp.n_pix_slots;
+        if (live) {  // level 0 too: k_trace_easy has stored the primary rays it listed
             const RayRec r = ray_at(w, level, i);
             o = mk(r.ox, r.oy, r.oz);
             d = mk(r.dx, r.dy, r.dz);
@@ -1005,8 +1001,8 @@ __global__ __launch_bounds__(kBlock) void k_resolve(FrameParams fp, Work w, uint
                                                     int32_t *out_tri) {
     uint32_t ps = blockIdx.x * kBlock + threadIdx.x;
     if (ps >= fp.n_pix_slots) return;
-    uint32_t x, y;
-    if (!slot_to_pixel(fp, ps, x, y)) return;
+    uint32_t x, y, frame, part_slot;
+    if (!slot_to_pixel(fp, ps, x, y, frame, part_slot)) return;
     Col c;
     if (fp.aa) {
         c = Col{0, 0, 0};
@@ -1018,7 +1014,7 @@ __global__ __launch_bounds__(kBlock) void k_resolve(FrameParams fp, Work w, uint
     } else {
         c = resolve_chain(w, ps, fp.max_rec);
     }
-    size_t idx = fp.layout ? (size_t)fp.q0 * fp.tile_w * fp.tile_h + ps : (size_t)y * fp.W + x;
+    size_t idx = fp.layout ? (size_t)frame * fp.part_slots + part_slot : ((size_t)frame * fp.H + y) * fp.W + x;
     pixels[idx] = c_pack(c);
     if (out_shape) out_shape[idx] = w.id_shape[ps];
     if (out_tri) out_tri[idx] = w.id_tri[ps];
@@ -1028,13 +1024,17 @@ __global__ __launch_bounds__(kBlock) void k_resolve(FrameParams fp, Work w, uint
 __global__ __launch_bounds__(kBlock) void k_assemble(FrameParams fp, const uint32_t *gathered, uint32_t part_slots,
                                                      uint32_t *frame) {
     uint32_t ps = blockIdx.x * kBlock + threadIdx.x;
-    uint32_t part = blockIdx.y;
+    uint32_t part = blockIdx.y, b = blockIdx.z;
     if (ps >= part_slots) return;
     fp.part_index = part;
     fp.q0 = 0;
-    uint32_t x, y;
-    if (!slot_to_pixel(fp, ps, x, y)) return;
-    frame[(size_t)y * fp.W + x] = gathered[(size_t)part * part_slots + ps];
+    fp.n_frames = 1;
+    const uint32_t n_tiles = fp.tiles_x * fp.tiles_y;
+    if (part >= n_tiles) return;
+    fp.my_tiles = (n_tiles - part + fp.part_count - 1) / fp.part_count;
+    uint32_t x, y, f0, slot;
+    if (!slot_to_pixel(fp, ps, x, y, f0, slot)) return;
+    frame[((size_t)b * fp.H + y) * fp.W + x] = gathered[((size_t)part * gridDim.z + b) * part_slots + ps];
 }
 
 // ---- probe kernels (KAT parity of single device functions) ----
@@ -1121,6 +1121,7 @@ struct rthip_ctx {
     std::atomic<float> progress{0.f};
     rthip_stats last{};
     int count_kd = 0;
+    uint32_t last_frames = 1;  // frames of the last render call (statistics are per call)
     size_t chunk_rays = kMaxLevelRays;
     // one frame = ~20 dependent launches; replaying them as a HIP graph cuts the host cost of a frame from ~80 us to
     // one launch (what bounds small frames and the per-GPU share of a multi-GPU frame).  The graph is re-captured
@@ -1395,11 +1396,14 @@ static int check_params(const rthip_camera *cam, const rthip_params *p) {
     return 0;
 }
 
-// renders this context's part into d_pixels (device, W*H) and optionally device id images
-static int render_frame(rthip_ctx *c, const rthip_camera *cam, const rthip_params *p, uint32_t *d_pixels,
+// renders this context's part of n_frames frames (one camera each) into d_pixels (device; frame after frame, each
+// W*H or, tile-compact, rthip_part_pixels) and optionally device id images (single frames only)
+static int render_frame(rthip_ctx *c, const rthip_camera *cam, uint32_t n_frames, const rthip_params *p, uint32_t *d_pixels,
                         int32_t *d_shape, int32_t *d_tri) {
     int rc = check_params(cam, p);
     if (rc) return rc;
+    if (n_frames == 0 || n_frames > RTHIP_MAX_BATCH) return fail(RTHIP_E_INVALID, "rthip_render: %u frames per call, limit %d", n_frames, RTHIP_MAX_BATCH);
+    if (n_frames > 1 && (d_shape || d_tri)) return fail(RTHIP_E_INVALID, "rthip_render: id images are for single frames");
     if (!c->has_scene) return fail(RTHIP_E_STATE, "rthip_render: no scene uploaded");
     if (set_device(c)) return RTHIP_E_HIP;
     c->interrupt.store(0);
@@ -1407,7 +1411,9 @@ static int render_frame(rthip_ctx *c, const rthip_camera *cam, const rthip_param
 
     FrameParams fp;
     memset(&fp, 0, sizeof fp);
-    fp.cam = *cam;
+    for (uint32_t b = 0; b < n_frames; b++) fp.cams[b] = cam[b];
+    fp.n_frames = n_frames;
+    fp.part_slots = (uint32_t)rthip_part_pixels(p);
     fp.W = p->width;
     fp.H = p->height;
     fp.max_rec = p->renderer == RTHIP_RENDER_RAYTRACER ? p->max_recursion : 0;
@@ -1422,7 +1428,9 @@ static int render_frame(rthip_ctx *c, const rthip_camera *cam, const rthip_param
     fp.count_kd = c->count_kd;
     fp.layout = (d_shape || d_tri) ? 0 : p->layout;
     const uint32_t n_tiles = fp.tiles_x * fp.tiles_y;
-    const uint32_t my_tiles = n_tiles > fp.part_index ? (n_tiles - fp.part_index + fp.part_count - 1) / fp.part_count : 0;
+    const uint32_t frame_tiles = n_tiles > fp.part_index ? (n_tiles - fp.part_index + fp.part_count - 1) / fp.part_count : 0;
+    fp.my_tiles = frame_tiles ? frame_tiles : 1;
+    const uint32_t my_tiles = frame_tiles * n_frames;  // tile ordinals of the whole batch
     const uint32_t per_tile = fp.tile_w * fp.tile_h;
     const uint32_t spp = fp.aa ? 9 : 1;
     const uint32_t levels = fp.max_rec + 1;
@@ -1484,7 +1492,7 @@ static int render_frame(rthip_ctx *c, const rthip_camera *cam, const rthip_param
         auto put = [&](const void *ptr, size_t n) { key.insert(key.end(), (const unsigned char *)ptr, (const unsigned char *)ptr + n); };
         const void *ptrs[] = {d_pixels, d_shape, d_tri, c->rec.p, c->child.p, c->rays.p, c->counts.p, c->stats.p, c->block_stats.p,
                               c->ids.p, c->hits.p, c->redo.p};
-        put(cam, sizeof *cam);
+        put(cam, sizeof *cam * n_frames);
         put(p, sizeof *p);
         put(ptrs, sizeof ptrs);
         put(&c->scene_generation, sizeof c->scene_generation);
@@ -1495,6 +1503,7 @@ static int render_frame(rthip_ctx *c, const rthip_camera *cam, const rthip_param
             HIP_TRY(hipEventRecord(c->ev1, c->stream));
             c->last.pixels = (uint64_t)my_tiles * per_tile;
             c->last.launches_trace = 0;
+            c->last_frames = n_frames;
             return 0;
         }
     }
@@ -1595,6 +1604,7 @@ static int render_frame(rthip_ctx *c, const rthip_camera *cam, const rthip_param
         if (graph) (void)hipGraphDestroy(graph);
         if (e == hipSuccess && erc == 0 && c->graph_exec) {
             c->graph_key = key;
+            c->last_frames = n_frames;
             HIP_TRY(hipEventRecord(c->ev0, c->stream));
             HIP_TRY(hipGraphLaunch(c->graph_exec, c->stream));
             HIP_TRY(hipEventRecord(c->ev1, c->stream));
@@ -1608,6 +1618,7 @@ static int render_frame(rthip_ctx *c, const rthip_camera *cam, const rthip_param
         ev_used = 0;
         pixels_done = 0;
     }
+    c->last_frames = n_frames;
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
     rc = enqueue();
     if (rc) return rc;
@@ -1637,6 +1648,7 @@ static int finish_stats(rthip_ctx *c, const rthip_params *p) {
         uint32_t ww = p->width - w0 < tw ? p->width - w0 : tw, hh = p->height - h0 < th ? p->height - h0 : th;
         px += (uint64_t)ww * hh;
     }
+    px *= c->last_frames;
     c->last.pixels = px;
     c->last.rays_primary = px * (p->aa_mode ? 9 : 1);
     {
@@ -1697,8 +1709,12 @@ static int finish_stats(rthip_ctx *c, const rthip_params *p) {
 }
 
 int rthip_render_device(rthip_ctx *c, const rthip_camera *cam, const rthip_params *p, void *d_pixels, int sync) {
+    return rthip_render_batch_device(c, cam, 1, p, d_pixels, sync);
+}
+
+int rthip_render_batch_device(rthip_ctx *c, const rthip_camera *cams, uint32_t n_frames, const rthip_params *p, void *d_pixels, int sync) {
     if (!c || !d_pixels) return fail(RTHIP_E_INVALID, "rthip_render_device: null argument");
-    int rc = render_frame(c, cam, p, (uint32_t *)d_pixels, nullptr, nullptr);
+    int rc = render_frame(c, cams, n_frames, p, (uint32_t *)d_pixels, nullptr, nullptr);
     if (rc) return rc;
     if (sync) return finish_stats(c, p);
     return 0;
@@ -1723,7 +1739,7 @@ int rthip_render(rthip_ctx *c, const rthip_camera *cam, const rthip_params *p, u
     if (ids) HIP_TRY(hipMemsetAsync(d_sh, 0xff, sizeof(int32_t) * 2 * npx, c->stream));
     rthip_params pf = *p;
     pf.layout = 0;
-    rc = render_frame(c, cam, &pf, d_px, d_sh, d_tr);
+    rc = render_frame(c, cam, 1, &pf, d_px, d_sh, d_tr);
     if (rc) return rc;
     rc = finish_stats(c, p);
     if (rc) return rc;
@@ -1741,7 +1757,12 @@ uint64_t rthip_part_pixels(const rthip_params *p) {
 }
 
 int rthip_assemble(rthip_ctx *c, const rthip_params *p, const void *d_gathered, void *d_frame, int sync) {
+    return rthip_assemble_batch(c, p, 1, d_gathered, d_frame, sync);
+}
+
+int rthip_assemble_batch(rthip_ctx *c, const rthip_params *p, uint32_t n_frames, const void *d_gathered, void *d_frame, int sync) {
     if (!c || !p || !d_gathered || !d_frame) return fail(RTHIP_E_INVALID, "rthip_assemble: null argument");
+    if (n_frames == 0 || n_frames > RTHIP_MAX_BATCH) return fail(RTHIP_E_INVALID, "rthip_assemble: %u frames per call, limit %d", n_frames, RTHIP_MAX_BATCH);
     rthip_camera dummy;
     memset(&dummy, 0, sizeof dummy);
     int rc = check_params(&dummy, p);
@@ -1757,7 +1778,7 @@ int rthip_assemble(rthip_ctx *c, const rthip_params *p, const void *d_gathered, 
     fp.tiles_x = (fp.W + fp.tile_w - 1) / fp.tile_w;
     fp.tiles_y = (fp.H + fp.tile_h - 1) / fp.tile_h;
     uint32_t part_slots = (uint32_t)rthip_part_pixels(p);
-    hipLaunchKernelGGL(k_assemble, dim3((part_slots + kBlock - 1) / kBlock, p->part_count), dim3(kBlock), 0, c->stream, fp,
+    hipLaunchKernelGGL(k_assemble, dim3((part_slots + kBlock - 1) / kBlock, p->part_count, n_frames), dim3(kBlock), 0, c->stream, fp,
                        (const uint32_t *)d_gathered, part_slots, (uint32_t *)d_frame);
     HIP_TRY(hipGetLastError());
     if (sync) HIP_TRY(hipStreamSynchronize(c->stream));

@@ -18,7 +18,8 @@ SYMBOLS = ["rthip_create", "rthip_destroy", "rthip_last_error", "rthip_upload_sc
            "rthip_render_device", "rthip_stream", "rthip_synchronize", "rthip_progress", "rthip_interrupt",
            "rthip_get_stats", "rthip_probe_cast", "rthip_probe_noise", "rthip_probe_material",
            "rthip_probe_background", "rthip_probe_raycast", "rthip_probe_arith", "rthip_version",
-           "rthip_part_pixels", "rthip_assemble"]
+           "rthip_part_pixels", "rthip_assemble", "rthip_render_batch_device", "rthip_assemble_batch"]
+MAX_BATCH = 8  # RTHIP_MAX_BATCH
 
 
 class Camera(C.Structure):
@@ -61,6 +62,13 @@ def lib():
     if not os.path.exists(RTHIP_SO):
         raise RuntimeError(f"{RTHIP_SO} is missing: build it first (python -c 'import __graft_entry__ as g; g.build()'); "
                            "the Raycast path has no CPU fallback")
+    try:
+        # One HIP runtime per process: torch ships its own libamdhip64 / libhsa-runtime64 and finds no GPU when another
+        # copy (the /opt/rocm one librthip.so would pull in) has opened the device first.  Loaded after torch, librthip.so
+        # binds to torch's copy.  Without torch in the process there is nothing to collide with.
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(RTHIP_SO)
     vp = C.c_void_p
     L.rthip_create.argtypes = [C.c_int, C.POINTER(vp)]
@@ -73,6 +81,8 @@ def lib():
     L.rthip_part_pixels.argtypes = [C.POINTER(Params)]
     L.rthip_part_pixels.restype = C.c_uint64
     L.rthip_assemble.argtypes = [vp, C.POINTER(Params), vp, vp, C.c_int]
+    L.rthip_render_batch_device.argtypes = [vp, C.POINTER(Camera), C.c_uint32, C.POINTER(Params), vp, C.c_int]
+    L.rthip_assemble_batch.argtypes = [vp, C.POINTER(Params), C.c_uint32, vp, vp, C.c_int]
     L.rthip_stream.argtypes = [vp]
     L.rthip_stream.restype = vp
     L.rthip_synchronize.argtypes = [vp]
@@ -146,6 +156,14 @@ class Context:
 
     def assemble(self, params, d_gathered_ptr, d_frame_ptr, sync=False):
         self._check(self.L.rthip_assemble(self.h, C.byref(params), C.c_void_p(d_gathered_ptr), C.c_void_p(d_frame_ptr), int(sync)))
+
+    def render_batch_device(self, cams, params, d_pixels_ptr, sync=False):
+        """cams: sequence of Camera (1..MAX_BATCH); d_pixels_ptr: len(cams) frame (or part) buffers one after the other."""
+        arr = cams if isinstance(cams, C.Array) else (Camera * len(cams))(*cams)
+        self._check(self.L.rthip_render_batch_device(self.h, arr, len(arr), C.byref(params), C.c_void_p(d_pixels_ptr), int(sync)))
+
+    def assemble_batch(self, params, n_frames, d_gathered_ptr, d_frames_ptr, sync=False):
+        self._check(self.L.rthip_assemble_batch(self.h, C.byref(params), n_frames, C.c_void_p(d_gathered_ptr), C.c_void_p(d_frames_ptr), int(sync)))
 
     def synchronize(self):
         self._check(self.L.rthip_synchronize(self.h))

@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""What ONE rank of an N-GPU run costs per frame, measured on one GPU: renders part 0 of N of config 3 in batches of B
+frames with F batches in flight (render + assemble of a part-major buffer; the RCCL gather itself is not in it).
+Gives the per-rank floor of the strong-scaling bench before an 8-GPU node is available.
+usage: gpu_rank_share.py [N ...]   env RANKSHARE_F=1,2,3  RANKSHARE_B=1,2,4,8  RANKSHARE_K=frames"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from raytracing_amd import device, host, scenes
+import torch
+W, H, MR = 1920, 1080, 3
+sd, _ = scenes.config(3)
+hs = host.HostScene(sd); desc = hs.flatten(); cam = hs.camera(W, H)
+Fs = [int(f) for f in os.environ.get("RANKSHARE_F", "1,2,3").split(",")]
+Bs = [int(f) for f in os.environ.get("RANKSHARE_B", "1,2,4,8").split(",")]
+K = int(os.environ.get("RANKSHARE_K", "480"))
+for N in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]:
+    prm = device.make_params(W, H, MR, part_index=0, part_count=N, layout=1)
+    px = device.part_pixels(prm)
+    for B in Bs:
+        cams = (device.Camera * B)(*([cam] * B))
+        for F in Fs:
+            ctxs = [device.Context(0) for _ in range(F)]
+            for c in ctxs: c.upload(desc)
+            mine = [torch.zeros(px * B, dtype=torch.int32, device="cuda") for _ in range(F)]
+            gath = [torch.zeros(px * N * B, dtype=torch.int32, device="cuda") for _ in range(F)]
+            frm = [torch.zeros(W * H * B, dtype=torch.int32, device="cuda") for _ in range(F)]
+            def step(k):
+                j = k % F
+                ctxs[j].render_batch_device(cams, prm, mine[j].data_ptr(), sync=False)
+                ctxs[j].assemble_batch(prm, B, gath[j].data_ptr(), frm[j].data_ptr(), sync=False)
+            def sync():
+                for c in ctxs: c.synchronize()
+            for k in range(4 * F): step(k)
+            sync(); t0 = time.perf_counter()
+            for k in range(K // B): step(k)
+            sync(); dt = (time.perf_counter() - t0) / (K // B * B) * 1e3
+            print(f"parts={N} batch={B} inflight={F}: {dt:.4f} ms/frame  (0.595/N = {0.595 / N:.4f})", flush=True)
+            for c in ctxs: c.close()
