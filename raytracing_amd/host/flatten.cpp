@@ -7,7 +7,10 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <future>
 #include <map>
+
+#include "re/threads.hpp"
 
 namespace re {
 namespace {
@@ -150,12 +153,20 @@ struct Flattener {
         }
         out.kd_bounds.insert(out.kd_bounds.end(), kd.bounds.begin(), kd.bounds.end());
         out.kd_refs.insert(out.kd_refs.end(), kd.refs.begin(), kd.refs.end());
-        for (unsigned a = 0; a < 3; a++) {  // plane coordinates of every kd box on axis a
-            std::vector<double> planes = {kd.bounds[a], kd.bounds[3 + a]};
-            for (const auto &n : kd.nodes)
-                if (!(n.info & RTHIP_KD_LEAF) && (n.info & RTHIP_KD_AXIS_MASK) == a) planes.push_back(n.split);
-            std::sort(planes.begin(), planes.end());
-            planes.erase(std::unique(planes.begin(), planes.end()), planes.end());
+        std::vector<double> axis_planes[3];
+        std::future<void> sorted[3];
+        for (unsigned a = 0; a < 3; a++)  // plane coordinates of every kd box on axis a
+            sorted[a] = std::async(std::launch::async, [&, a] {
+                std::vector<double> &planes = axis_planes[a];
+                planes = {kd.bounds[a], kd.bounds[3 + a]};
+                for (const auto &n : kd.nodes)
+                    if (!(n.info & RTHIP_KD_LEAF) && (n.info & RTHIP_KD_AXIS_MASK) == a) planes.push_back(n.split);
+                std::sort(planes.begin(), planes.end());
+                planes.erase(std::unique(planes.begin(), planes.end()), planes.end());
+            });
+        for (unsigned a = 0; a < 3; a++) {
+            sorted[a].get();
+            const std::vector<double> &planes = axis_planes[a];
             m.plane_base[a] = (uint32_t)out.kd_planes.size();
             m.plane_count[a] = (uint32_t)planes.size();
             out.kd_planes.insert(out.kd_planes.end(), planes.begin(), planes.end());
@@ -182,24 +193,22 @@ struct Flattener {
             r.d00 = t.D00(); r.d01 = t.D01(); r.d11 = t.D11(); r.inv_den = t.InvDen();
             return r;
         };
-        for (uint32_t ti : bvh.order) {
-            out.bvh_tris.push_back(pack(tris[ti]));
-            out.bvh_tri_index.push_back(ti);
-        }
-        for (const Triangle &t : tris) {
-            rthip_tri r;
-            Put(r.v0, t.Vertices[0]);
-            Put(r.face_normal, t.FaceNormal);
-            Put(r.e0, t.Edges[0]);
-            Put(r.e1, t.Edges[1]);
-            r.d00 = t.D00(); r.d01 = t.D01(); r.d11 = t.D11(); r.inv_den = t.InvDen();
-            out.tris.push_back(r);
-            for (int k = 0; k < 3; k++) {
-                out.tri_normals.push_back(t.Normals[k].X);
-                out.tri_normals.push_back(t.Normals[k].Y);
-                out.tri_normals.push_back(t.Normals[k].Z);
+        const size_t n = tris.size(), b0 = out.bvh_tris.size(), t0 = out.tris.size();
+        out.bvh_tris.resize(b0 + n);
+        out.bvh_tri_index.resize(b0 + n);
+        out.tris.resize(t0 + n);
+        out.tri_normals.resize(9 * (t0 + n));
+        ParallelSlices(n, [&](size_t i0, size_t i1) {
+            for (size_t i = i0; i < i1; i++) {
+                const uint32_t ti = bvh.order[i];
+                out.bvh_tris[b0 + i] = pack(tris[ti]);
+                out.bvh_tri_index[b0 + i] = ti;
+                const Triangle &t = tris[i];
+                out.tris[t0 + i] = pack(t);
+                double *nn = &out.tri_normals[9 * (t0 + i)];
+                for (int k = 0; k < 3; k++) Put(nn + 3 * k, t.Normals[k]);
             }
-        }
+        });
         idx = (int32_t)out.meshes.size();
         out.meshes.push_back(m);
         mesh_index[mesh] = idx;

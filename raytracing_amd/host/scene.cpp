@@ -2,11 +2,18 @@
 // caches (Scene.cpp:509-523) and the kd-tree with the reference's splitting rules
 // (Scene.cpp:18-95), emitted directly in the flat pre-order layout the device walks.
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cmath>
+#include <future>
+#include <mutex>
+#include <thread>
 #include <cstdlib>
 #include <cstring>
 
 #include "re/scene.hpp"
+#include "re/threads.hpp"
 #include "rthip.h"
 
 namespace re {
@@ -99,16 +106,37 @@ Triangle &Mesh::AddTriangle() {
 namespace {
 // Builder: same decisions as KDTreeTriangle's constructor (Scene.cpp:18-95) on triangle INDEX lists
 // (the reference copies 272-byte triangles by value; the order of each list is the same).
+//
+// Sub-trees are independent, so the two children of a big node are built on two threads, each into a flat tree of
+// its own, and appended in pre-order afterwards (left at me + 1, then right) with their links rebased.  The result
+// is the array a single-threaded build writes: every decision of a node depends on its own triangle list only.
 struct KdBuilder {
     const std::vector<Triangle> &tris;
     KdTreeFlat &out;
+    static constexpr size_t kTaskMin = 1u << 15;  // triangles below which a sub-tree is not worth a thread
+
+    // appends the flat tree `sub` (indices local to it) to `out`; returns the index its root gets
+    uint32_t Append(const KdTreeFlat &sub) {
+        const uint32_t nb = (uint32_t)out.nodes.size(), rb = (uint32_t)out.refs.size();
+        for (const auto &n : sub.nodes) {
+            auto m = n;
+            if (m.info & RTHIP_KD_LEAF) m.link += rb;
+            else if (m.info & RTHIP_KD_HAS_RIGHT) m.link += nb;
+            out.nodes.push_back(m);
+        }
+        out.depth.insert(out.depth.end(), sub.depth.begin(), sub.depth.end());
+        out.bounds.insert(out.bounds.end(), sub.bounds.begin(), sub.bounds.end());
+        out.refs.insert(out.refs.end(), sub.refs.begin(), sub.refs.end());
+        out.max_depth = std::max(out.max_depth, sub.max_depth);
+        return nb;
+    }
 
     void Leaf(uint32_t me, const std::vector<uint32_t> &list) {
         out.nodes[me].link = (uint32_t)out.refs.size();
         out.nodes[me].info = RTHIP_KD_LEAF | ((uint32_t)list.size() << RTHIP_KD_COUNT_SHIFT);
         out.refs.insert(out.refs.end(), list.begin(), list.end());
     }
-    uint32_t Build(const std::vector<uint32_t> &list, const BoundingBox &bounds, unsigned depth) {
+    uint32_t Build(const std::vector<uint32_t> &list, const BoundingBox &bounds, unsigned depth, int fork = 0) {
         const uint32_t me = (uint32_t)out.nodes.size();
         out.nodes.push_back({0.0, 0, 0});
         out.depth.push_back(depth);
@@ -144,6 +172,16 @@ struct KdBuilder {
         }
         out.nodes[me].split = median;
         uint32_t info = axis;
+        if (fork > 0 && left.size() >= kTaskMin && right.size() >= kTaskMin) {
+            KdTreeFlat lsub, rsub;
+            auto lf = std::async(std::launch::async, [&] { KdBuilder{tris, lsub}.Build(left, lb, depth + 1, fork - 1); });
+            KdBuilder{tris, rsub}.Build(right, rb, depth + 1, fork - 1);
+            lf.get();
+            Append(lsub);  // lands at me + 1
+            out.nodes[me].link = Append(rsub);
+            out.nodes[me].info = info | RTHIP_KD_HAS_LEFT | RTHIP_KD_HAS_RIGHT;
+            return me;
+        }
         if (!left.empty()) {
             info |= RTHIP_KD_HAS_LEFT;
             Build(left, lb, depth + 1);  // lands at me + 1
@@ -185,6 +223,7 @@ struct BvhBuilder {
     BvhFlat &out;
     std::vector<double> tlo, thi, cen;  // 3 per triangle
     std::vector<Node2> bin;             // the binary tree
+    static constexpr uint32_t kTaskMin = 1u << 15;  // triangles below which a sub-tree is not worth a thread
 
     static float Down(double x) {
         float f = (float)x;
@@ -200,16 +239,22 @@ struct BvhBuilder {
         const size_t n = tris.size();
         tlo.resize(3 * n); thi.resize(3 * n); cen.resize(3 * n);
         out.order.resize(n);
+        std::mutex mu;
         double amax = 0;
-        for (size_t i = 0; i < n; i++) {
-            out.order[i] = (uint32_t)i;
-            for (int a = 0; a < 3; a++) {
-                double v0 = tris[i].Vertices[0][a], v1 = tris[i].Vertices[1][a], v2 = tris[i].Vertices[2][a];
-                double l = std::min(v0, std::min(v1, v2)), h = std::max(v0, std::max(v1, v2));
-                tlo[3 * i + a] = l; thi[3 * i + a] = h; cen[3 * i + a] = 0.5 * (l + h);
-                amax = std::max(amax, std::max(std::fabs(l), std::fabs(h)));
+        ParallelSlices(n, [&](size_t i0, size_t i1) {
+            double am = 0;
+            for (size_t i = i0; i < i1; i++) {
+                out.order[i] = (uint32_t)i;
+                for (int a = 0; a < 3; a++) {
+                    double v0 = tris[i].Vertices[0][a], v1 = tris[i].Vertices[1][a], v2 = tris[i].Vertices[2][a];
+                    double l = std::min(v0, std::min(v1, v2)), h = std::max(v0, std::max(v1, v2));
+                    tlo[3 * i + a] = l; thi[3 * i + a] = h; cen[3 * i + a] = 0.5 * (l + h);
+                    am = std::max(am, std::max(std::fabs(l), std::fabs(h)));
+                }
             }
-        }
+            std::lock_guard<std::mutex> g(mu);
+            amax = std::max(amax, am);
+        });
         out.abs_max = Up(amax);
     }
     Box BoundsOf(uint32_t lo, uint32_t hi) const {
@@ -217,8 +262,10 @@ struct BvhBuilder {
         for (uint32_t i = lo; i < hi; i++) b.Grow(&tlo[3 * out.order[i]], &thi[3 * out.order[i]]);
         return b;
     }
-    // builds the binary subtree over order[lo,hi); returns the child word and its box
-    uint32_t Build(uint32_t lo, uint32_t hi, unsigned depth, Box &box) {
+    // builds the binary subtree over order[lo,hi) into `bin`; returns the child word and its box.  fork > 0: the two
+    // halves of a big range (disjoint slices of `order`) are built on two threads, the left one into a node array of
+    // its own that is appended afterwards with its links rebased; the tree does not depend on the thread count.
+    uint32_t Build(std::vector<Node2> &bin, uint32_t lo, uint32_t hi, unsigned depth, Box &box, int fork) {
         box = BoundsOf(lo, hi);
         const uint32_t n = hi - lo;
         auto leaf = [&]() { return RTHIP_BVH_LEAF | ((n - 1) << RTHIP_BVH_COUNT_SHIFT) | lo; };
@@ -234,12 +281,26 @@ struct BvhBuilder {
                 Box bb[kBins];
                 uint32_t cnt[kBins] = {0};
                 const double k = kBins / ext;
-                for (uint32_t i = lo; i < hi; i++) {
-                    const uint32_t t = out.order[i];
-                    int b = (int)((cen[3 * t + a] - cb.lo[a]) * k);
-                    b = b < 0 ? 0 : (b >= kBins ? kBins - 1 : b);
-                    cnt[b]++;
-                    bb[b].Grow(&tlo[3 * t], &thi[3 * t]);
+                auto bin_slice = [&](size_t i0, size_t i1, Box *sb, uint32_t *sc) {
+                    for (size_t i = i0; i < i1; i++) {
+                        const uint32_t t = out.order[i];
+                        int b = (int)((cen[3 * t + a] - cb.lo[a]) * k);
+                        b = b < 0 ? 0 : (b >= kBins ? kBins - 1 : b);
+                        sc[b]++;
+                        sb[b].Grow(&tlo[3 * t], &thi[3 * t]);
+                    }
+                };
+                if (fork > 0 && n >= 8 * kTaskMin) {  // the top of the tree: few nodes, long loops (counts and min / max merge exactly)
+                    std::mutex mu;
+                    ParallelSlices(n, [&](size_t i0, size_t i1) {
+                        Box sb[kBins];
+                        uint32_t sc[kBins] = {0};
+                        bin_slice(lo + i0, lo + i1, sb, sc);
+                        std::lock_guard<std::mutex> g(mu);
+                        for (int b = 0; b < kBins; b++) { bb[b].Grow(sb[b]); cnt[b] += sc[b]; }
+                    });
+                } else {
+                    bin_slice(lo, hi, bb, cnt);
                 }
                 double right_area[kBins];
                 uint32_t right_cnt[kBins];
@@ -281,8 +342,23 @@ struct BvhBuilder {
         const uint32_t me = (uint32_t)bin.size();
         bin.emplace_back();
         Box b0, b1;
-        const uint32_t c0 = Build(lo, mid, depth + 1, b0);
-        const uint32_t c1 = Build(mid, hi, depth + 1, b1);
+        uint32_t c0, c1;
+        if (fork > 0 && mid - lo >= kTaskMin && hi - mid >= kTaskMin) {
+            std::vector<Node2> lbin;
+            auto lf = std::async(std::launch::async, [&] { return Build(lbin, lo, mid, depth + 1, b0, fork - 1); });
+            c1 = Build(bin, mid, hi, depth + 1, b1, fork - 1);
+            c0 = lf.get();
+            const uint32_t base = (uint32_t)bin.size();
+            for (Node2 &n : lbin) {
+                for (uint32_t &c : n.c)
+                    if (!(c & RTHIP_BVH_LEAF)) c += base;
+                bin.push_back(n);
+            }
+            if (!(c0 & RTHIP_BVH_LEAF)) c0 += base;
+        } else {
+            c0 = Build(bin, lo, mid, depth + 1, b0, 0);
+            c1 = Build(bin, mid, hi, depth + 1, b1, 0);
+        }
         bin[me].b[0] = b0; bin[me].b[1] = b1;
         bin[me].c[0] = c0; bin[me].c[1] = c1;
         return me;
@@ -325,7 +401,7 @@ struct BvhBuilder {
         if (tris.empty()) return;
         Prepare();
         Box root;
-        const uint32_t w = Build(0, (uint32_t)tris.size(), 0, root);
+        const uint32_t w = Build(bin, 0, (uint32_t)tris.size(), 0, root, BuildForkDepth());
         if (w & RTHIP_BVH_LEAF) {  // tiny mesh: a root node whose only child is the single leaf
             out.nodes.emplace_back();
             for (int i = 0; i < 4; i++) {
@@ -349,21 +425,35 @@ struct BvhBuilder {
 void Mesh::Compile() {
     if (!m_Invalidated) return;
     // the bounding box starts at (0,0,0)/(0,0,0) and is never reset (Scene.cpp:391-406, Common.h:212)
-    Vector3 &mn = m_BoundingBox.Min, &mx = m_BoundingBox.Max;
-    for (Triangle &t : m_Triangles) {
-        t.Update();
-        for (const Vector3 &v : t.Vertices) {
-            mn.X = std::min(mn.X, v.X); mn.Y = std::min(mn.Y, v.Y); mn.Z = std::min(mn.Z, v.Z);
-            mx.X = std::max(mx.X, v.X); mx.Y = std::max(mx.Y, v.Y); mx.Z = std::max(mx.Z, v.Z);
+    // (min / max are exact and order-independent: slices on threads give the same box)
+    std::mutex mu;
+    ParallelSlices(m_Triangles.size(), [&](size_t i0, size_t i1) {
+        BoundingBox bb = m_BoundingBox;
+        Vector3 &mn = bb.Min, &mx = bb.Max;
+        for (size_t i = i0; i < i1; i++) {
+            Triangle &t = m_Triangles[i];
+            t.Update();
+            for (const Vector3 &v : t.Vertices) {
+                mn.X = std::min(mn.X, v.X); mn.Y = std::min(mn.Y, v.Y); mn.Z = std::min(mn.Z, v.Z);
+                mx.X = std::max(mx.X, v.X); mx.Y = std::max(mx.Y, v.Y); mx.Z = std::max(mx.Z, v.Z);
+            }
         }
-    }
+        std::lock_guard<std::mutex> g(mu);
+        Vector3 &gmn = m_BoundingBox.Min, &gmx = m_BoundingBox.Max;
+        gmn.X = std::min(gmn.X, mn.X); gmn.Y = std::min(gmn.Y, mn.Y); gmn.Z = std::min(gmn.Z, mn.Z);
+        gmx.X = std::max(gmx.X, mx.X); gmx.Y = std::max(gmx.Y, mx.Y); gmx.Z = std::max(gmx.Z, mx.Z);
+    });
+    auto T0 = std::chrono::steady_clock::now();
     m_KdTree = KdTreeFlat();
     std::vector<uint32_t> all(m_Triangles.size());
     for (size_t i = 0; i < all.size(); i++) all[i] = (uint32_t)i;
     KdBuilder builder{m_Triangles, m_KdTree};
-    builder.Build(all, m_BoundingBox, 0);
+    builder.Build(all, m_BoundingBox, 0, BuildForkDepth());
+    auto T1 = std::chrono::steady_clock::now();
     BvhBuilder bvh{m_Triangles, m_Bvh, {}, {}, {}, {}};
     bvh.Run();
+    auto T2 = std::chrono::steady_clock::now();
+    if (getenv("RE_BUILD_TIMING")) fprintf(stderr, "Mesh::Compile %zu tris: kd %.3f s, bvh %.3f s\n", m_Triangles.size(), std::chrono::duration<double>(T1 - T0).count(), std::chrono::duration<double>(T2 - T1).count());
     m_Invalidated = false;
 }
 

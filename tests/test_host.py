@@ -156,3 +156,36 @@ def test_bvh_is_complete_and_conservative(host_lib):
                 stack.append((c, clo, chi))
     assert visited == n_nodes
     assert seen.all()
+
+
+def _flat_arrays(desc):
+    import ctypes as C
+    class Desc(C.Structure):
+        _fields_ = [("shapes", C.c_void_p), ("n_shapes", C.c_uint32), ("meshes", C.c_void_p), ("n_meshes", C.c_uint32),
+                    ("kd_nodes", C.c_void_p), ("n_kd_nodes", C.c_uint64), ("kd_bounds", C.c_void_p), ("kd_refs", C.c_void_p),
+                    ("n_kd_refs", C.c_uint64), ("kd_planes", C.c_void_p), ("n_kd_planes", C.c_uint64), ("tris", C.c_void_p),
+                    ("n_tris", C.c_uint64), ("tri_normals", C.c_void_p), ("bvh_nodes", C.c_void_p), ("n_bvh_nodes", C.c_uint64),
+                    ("bvh_tris", C.c_void_p), ("bvh_tri_index", C.c_void_p)]
+    d = Desc.from_address(desc)
+    raw = lambda p, n: bytes((C.c_char * n).from_address(p))
+    return {"kd_nodes": raw(d.kd_nodes, 16 * d.n_kd_nodes), "kd_bounds": raw(d.kd_bounds, 48 * d.n_kd_nodes),
+            "kd_refs": raw(d.kd_refs, 4 * d.n_kd_refs), "kd_planes": raw(d.kd_planes, 8 * d.n_kd_planes),
+            "tris": raw(d.tris, 128 * d.n_tris), "tri_normals": raw(d.tri_normals, 72 * d.n_tris),
+            "bvh_nodes": raw(d.bvh_nodes, 128 * d.n_bvh_nodes), "bvh_tris": raw(d.bvh_tris, 128 * d.n_tris),
+            "bvh_tri_index": raw(d.bvh_tri_index, 4 * d.n_tris)}, (d.n_tris, d.n_kd_nodes, d.n_bvh_nodes)
+
+
+def test_threaded_scene_build_gives_the_single_threaded_arrays(host_lib, monkeypatch):
+    """Mesh::Compile builds big sub-trees of the kd-tree and of the BVH on host threads (and bins the top BVH nodes in
+    slices); every flattened array must be byte-identical to the single-threaded build (the kd-tree's splits are the
+    reference's: sequential sums in triangle order per node)."""
+    sd = scenes.config(4, cells=384)[0]   # 294 912 triangles: above the fork and the sliced-binning thresholds
+    out = {}
+    for threads in ("1", "8", "3"):
+        monkeypatch.setenv("RE_BUILD_THREADS", threads)
+        hs = host.HostScene(sd)
+        out[threads], counts = _flat_arrays(hs.flatten())
+        assert counts[0] == 2 * 384 * 384 and counts[1] > 1000 and counts[2] > counts[0] // 16
+    for threads in ("8", "3"):
+        for k, v in out["1"].items():
+            assert out[threads][k] == v, f"{k} differs with {threads} build threads"
