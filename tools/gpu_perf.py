@@ -11,8 +11,9 @@ from raytracing_amd import device, host, scenes
 HASHES = os.path.join(scenes.GOLDEN_DIR, "frame_hashes.json")
 known = json.load(open(HASHES)) if os.path.exists(HASHES) else {}
 cases = [("cfg3", lambda: scenes.config(3), {}), ("cfg3close", lambda: scenes.config(3, cam_z=2.2), {}),
-         ("cfg2", lambda: scenes.config(2), {}), ("cfg4", lambda: scenes.config(4), {})]
-only = sys.argv[1:] or [c[0] for c in cases]
+         ("cfg2", lambda: scenes.config(2), {}), ("cfg4", lambda: scenes.config(4), {}),
+         ("cfg5", lambda: scenes.config(5), {})]  # 10 M triangles at 8K on ONE GPU: only when asked for
+only = sys.argv[1:] or [c[0] for c in cases if c[0] != "cfg5"]
 out = {}
 for name, mk, _ in cases:
     if name not in only:
@@ -29,7 +30,7 @@ for name, mk, _ in cases:
     fb = torch.zeros(W * H, dtype=torch.int32, device="cuda")
     prm = device.make_params(W, H, mr)
     best = 1e9
-    for i in range(6):
+    for i in range(3 if name == "cfg5" else 6):
         ctx.render_device(cam, prm, fb.data_ptr(), sync=True)
         s = ctx.stats()
         best = min(best, s.ms_total)

@@ -128,8 +128,24 @@ def main_big():
     print("cfg4 sparse done in %.1fs" % (time.time() - t), flush=True)
 
 
+def main_big5():
+    """config 5 (five rotated / scaled 2 M-triangle meshes, 8K, MaxRecursion 8): 1024 seeded pixels through the reference"""
+    sd, kw = scenes.config(5)
+    t = time.time()
+    s = sd.build(R)
+    print("cfg5 scene built in %.1fs" % (time.time() - t), flush=True)
+    w, h = kw["width"], kw["height"]
+    xs, ys = sparse_pixels(w, h, 1024, 15)
+    r = s.render(w, h, ids=True, sub=(xs, ys), max_recursion=kw["max_recursion"])
+    np.savez_compressed(os.path.join(G, "sparse_cfg5.npz"), x=xs.astype(np.int16), y=ys.astype(np.int16), pixels=r["pixels"],
+                        shape=r["shape"].astype(np.int16), tri=r["tri"])
+    print("cfg5 sparse done in %.1fs" % (time.time() - t), flush=True)
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "big":
+    if len(sys.argv) > 1 and sys.argv[1] == "big5":
+        main_big5()
+    elif len(sys.argv) > 1 and sys.argv[1] == "big":
         main_big()
     else:
         main_small()
