@@ -1216,8 +1216,12 @@ static int validate_scene(const rthip_scene_desc *s, uint32_t *max_depth, uint32
     if (s->n_lights && !s->lights) BAD("lights is null");
     if (s->n_materials && !s->materials) BAD("materials is null");
     if (s->n_noises && !s->noises) BAD("noises is null");
-    if (s->n_meshes && (!s->meshes || !s->kd_nodes || !s->kd_bounds || !s->tris || !s->tri_normals)) BAD("mesh arrays are null");
-    if (s->n_meshes && s->n_tris && (!s->bvh_nodes || !s->bvh_tris || !s->bvh_tri_index)) BAD("bvh arrays are null");
+    // (a mesh without triangles is legal: Mesh::Compile builds a one-leaf kd-tree over nothing and no BVH)
+    if (s->n_meshes && !s->meshes) BAD("meshes is null");
+    if (s->n_kd_nodes && (!s->kd_nodes || !s->kd_bounds)) BAD("kd node arrays are null");
+    if (s->n_kd_refs && !s->kd_refs) BAD("kd_refs is null");
+    if (s->n_tris && (!s->tris || !s->tri_normals)) BAD("triangle arrays are null");
+    if (s->n_bvh_nodes && (!s->bvh_nodes || !s->bvh_tris || !s->bvh_tri_index)) BAD("bvh arrays are null");
     if (s->n_kd_refs && !s->kd_refs) BAD("kd_refs is null");
     if (s->n_perlin_tables && !s->perlin_tables) BAD("perlin_tables is null");
     if (s->n_worley_points && !s->worley_points) BAD("worley_points is null");
