@@ -734,10 +734,28 @@ __device__ __forceinline__ bool mesh_may_hit(const SceneView &sv, const rthip_me
     for (int c = 0; c < 4; c++) {
         const float blo[3] = {nd->c[c].lo[0], nd->c[c].lo[1], nd->c[c].lo[2]};
         const float bhi[3] = {nd->c[c].hi[0], nd->c[c].hi[1], nd->c[c].hi[2]};
+        const uint32_t child = nd->c[c].child;
         float tn;
         bool h;
         bvh_slab(blo, bhi, r, 3.0e38f, tn, h);
-        any = any || (h && nd->c[c].child != RTHIP_BVH_ABSENT);
+        h = h && child != RTHIP_BVH_ABSENT;
+        // second level: an interior child only counts if the ray also meets one of ITS four boxes (the node is the
+        // same for every lane: scalar loads; skipped when no lane of the wave reaches it)
+        if (!(child & RTHIP_BVH_LEAF) && __ballot(h)) {
+            uniform_node *n2 = nd + child;
+            bool any2 = false;
+#pragma unroll
+            for (int c2 = 0; c2 < 4; c2++) {
+                const float lo2[3] = {n2->c[c2].lo[0], n2->c[c2].lo[1], n2->c[c2].lo[2]};
+                const float hi2[3] = {n2->c[c2].hi[0], n2->c[c2].hi[1], n2->c[c2].hi[2]};
+                float tn2;
+                bool h2;
+                bvh_slab(lo2, hi2, r, 3.0e38f, tn2, h2);
+                any2 = any2 || (h2 && n2->c[c2].child != RTHIP_BVH_ABSENT);
+            }
+            h = h && any2;
+        }
+        any = any || h;
     }
     return any;
 }
