@@ -278,6 +278,13 @@ int rthip_upload_scene(rthip_ctx *ctx, const rthip_scene_desc *scene);
 int rthip_render(rthip_ctx *ctx, const rthip_camera *cam, const rthip_params *params,
                  uint32_t *out_pixels, int32_t *out_shape_id, int32_t *out_tri_index);
 
+/* Page-locked host memory (hipHostMalloc) for a buffer the caller keeps passing as out_pixels, so that the
+ * device-to-host copy of rthip_render runs at PCIe rate instead of through the runtime's staging buffers.
+ * replaces: the `new unsigned[w * h]` of the renderer-owned m_Pixels (Raytracer.cpp:20-25), which every Render
+ * returns.  Free with rthip_host_free before rthip_destroy. */
+int rthip_host_alloc(rthip_ctx *ctx, size_t bytes, void **out);
+int rthip_host_free(rthip_ctx *ctx, void *ptr);
+
 /* Same frame, output left in device memory (HBM): d_pixels is a device pointer to
  * width*height uint32 (row-major); only this part's pixels are written.  Asynchronous on the
  * context's stream unless `sync` is non-zero.  Used by bench.py and the multi-GPU gather. */

@@ -1771,6 +1771,22 @@ int rthip_render(rthip_ctx *c, const rthip_camera *cam, const rthip_params *p, u
     return 0;
 }
 
+int rthip_host_alloc(rthip_ctx *c, size_t bytes, void **out) {
+    if (!c || !out || !bytes) return fail(RTHIP_E_INVALID, "rthip_host_alloc: null argument");
+    *out = nullptr;
+    if (set_device(c)) return RTHIP_E_HIP;
+    HIP_TRY(hipHostMalloc(out, bytes, hipHostMallocDefault));
+    memset(*out, 0, bytes);
+    return 0;
+}
+int rthip_host_free(rthip_ctx *c, void *ptr) {
+    if (!c) return fail(RTHIP_E_INVALID, "rthip_host_free: null context");
+    if (!ptr) return 0;
+    if (set_device(c)) return RTHIP_E_HIP;
+    HIP_TRY(hipHostFree(ptr));
+    return 0;
+}
+
 uint64_t rthip_part_pixels(const rthip_params *p) {
     if (!p || p->width == 0 || p->height == 0 || p->part_count == 0) return 0;
     uint32_t tw = p->tile_w ? p->tile_w : 32, th = p->tile_h ? p->tile_h : 8;

@@ -18,7 +18,8 @@ SYMBOLS = ["rthip_create", "rthip_destroy", "rthip_last_error", "rthip_upload_sc
            "rthip_render_device", "rthip_stream", "rthip_synchronize", "rthip_progress", "rthip_interrupt",
            "rthip_get_stats", "rthip_probe_cast", "rthip_probe_noise", "rthip_probe_material",
            "rthip_probe_background", "rthip_probe_raycast", "rthip_probe_arith", "rthip_version",
-           "rthip_part_pixels", "rthip_assemble", "rthip_render_batch_device", "rthip_assemble_batch"]
+           "rthip_part_pixels", "rthip_assemble", "rthip_render_batch_device", "rthip_assemble_batch", "rthip_host_alloc",
+           "rthip_host_free"]
 MAX_BATCH = 8  # RTHIP_MAX_BATCH
 
 
@@ -83,6 +84,8 @@ def lib():
     L.rthip_assemble.argtypes = [vp, C.POINTER(Params), vp, vp, C.c_int]
     L.rthip_render_batch_device.argtypes = [vp, C.POINTER(Camera), C.c_uint32, C.POINTER(Params), vp, C.c_int]
     L.rthip_assemble_batch.argtypes = [vp, C.POINTER(Params), C.c_uint32, vp, vp, C.c_int]
+    L.rthip_host_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
+    L.rthip_host_free.argtypes = [vp, vp]
     L.rthip_stream.argtypes = [vp]
     L.rthip_stream.restype = vp
     L.rthip_synchronize.argtypes = [vp]
@@ -164,6 +167,16 @@ class Context:
 
     def assemble_batch(self, params, n_frames, d_gathered_ptr, d_frames_ptr, sync=False):
         self._check(self.L.rthip_assemble_batch(self.h, C.byref(params), n_frames, C.c_void_p(d_gathered_ptr), C.c_void_p(d_frames_ptr), int(sync)))
+
+    def host_pixels(self, width, height):
+        """(height, width) uint32 array in page-locked host memory (free with host_free before close())"""
+        p = C.c_void_p()
+        self._check(self.L.rthip_host_alloc(self.h, 4 * width * height, C.byref(p)))
+        arr = np.ctypeslib.as_array(C.cast(p, c_u32p), shape=(height, width))
+        return arr
+
+    def host_free(self, array):
+        self._check(self.L.rthip_host_free(self.h, C.c_void_p(array.ctypes.data)))
 
     def synchronize(self):
         self._check(self.L.rthip_synchronize(self.h))

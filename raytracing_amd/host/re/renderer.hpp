@@ -90,6 +90,9 @@ protected:
 private:
     void RenderThread(Scene *scene, std::promise<RenderStatus> p);
     rthip_ctx *m_Ctx = nullptr;
+    bool m_PixelsPinned = false;
+    int m_CreateRc = 0;
+    std::string m_CreateErr;
     std::mutex m_Mutex;
     std::condition_variable m_Idle;
     bool m_Busy = false;

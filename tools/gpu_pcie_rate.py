@@ -16,10 +16,17 @@ rays = ctx.stats(); rays = rays.rays_primary + rays.rays_shadow + rays.rays_refl
 t0 = time.perf_counter(); n = 100
 for _ in range(n): ctx.render(cam, prm, out=out)
 host_ms = (time.perf_counter() - t0) / n * 1e3
+pinned = ctx.host_pixels(W, H)
+for _ in range(5): ctx.render(cam, prm, out=pinned)
+t0 = time.perf_counter()
+for _ in range(n): ctx.render(cam, prm, out=pinned)
+pin_ms = (time.perf_counter() - t0) / n * 1e3
+assert np.array_equal(pinned, out)
+ctx.host_free(pinned)
 fb = torch.zeros(W * H, dtype=torch.int32, device="cuda")
 for _ in range(5): ctx.render_device(cam, prm, fb.data_ptr(), sync=True)
 t0 = time.perf_counter()
 for _ in range(n): ctx.render_device(cam, prm, fb.data_ptr(), sync=True)
 dev_ms = (time.perf_counter() - t0) / n * 1e3
-print(f"config 3, one frame at a time: host buffer out {host_ms:.3f} ms/frame = {rays/host_ms/1e3:.0f} Mrays/s (PCIe-inclusive); "
+print(f"config 3, one frame at a time: host buffer out {host_ms:.3f} ms/frame = {rays/host_ms/1e3:.0f} Mrays/s (PCIe-inclusive), page-locked {pin_ms:.3f} ms = {rays/pin_ms/1e3:.0f} Mrays/s; "
       f"HBM-resident {dev_ms:.3f} ms/frame = {rays/dev_ms/1e3:.0f} Mrays/s")
