@@ -1143,10 +1143,13 @@ struct rthip_ctx {
     size_t chunk_rays = kMaxLevelRays;
     // one frame = ~20 dependent launches; replaying them as a HIP graph cuts the host cost of a frame from ~80 us to
     // one launch (what bounds small frames and the per-GPU share of a multi-GPU frame).  The graph is re-captured
-    // when anything baked into it changes (camera, params, output pointers, scene, workspace).
+    // when anything baked into it changes (camera, params, output pointers, scene, workspace) - but only once the
+    // same key comes twice in a row: a camera that moves every frame (the Sandbox preview) keeps plain launches
+    // instead of paying a capture + instantiation (~1 ms) per frame.
     bool graphs_enabled = true;
     hipGraphExec_t graph_exec = nullptr;
     std::vector<unsigned char> graph_key;
+    std::vector<unsigned char> seen_key;  // key of the previous call: a graph is only captured for a key seen twice in a row
     uint64_t scene_generation = 0;
     int profile_launches = 0;
     std::vector<hipEvent_t> ev_pool;
@@ -1609,7 +1612,9 @@ static int render_frame(rthip_ctx *c, const rthip_camera *cam, uint32_t n_frames
     }
         return 0;
     };
-    if (use_graph) {  // capture once, then replay
+    const bool capture = use_graph && key == c->seen_key;
+    if (use_graph) c->seen_key = key;
+    if (capture) {  // capture once, then replay
         if (c->graph_exec) {
             (void)hipGraphExecDestroy(c->graph_exec);
             c->graph_exec = nullptr;
