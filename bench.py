@@ -9,7 +9,7 @@ region; every step traces the whole frame.  With N > 1 the frame is partitioned 
 HBM, the buffers are all-gathered over RCCL and assembled into the frame on the device; total work
 is fixed as N grows ("strong" scaling).
 
-Frames are traced in runs: one rthip_render_batch_device call takes --batch frames (default 8; the same camera for
+Frames are traced in runs: one rthip_render_batch_device call takes --batch frames (default 8 on one GPU, 16 on several; the same camera for
 all of them here, but every frame is traced in full — nothing is reused between frames) through ONE set of kernel
 launches, and --inflight calls (default 3) are in flight on separate HIP streams.  A run of frames is what a camera
 path rendered ahead of time looks like; it is also what keeps a GPU busy when its share of a 1080p frame is an
@@ -87,7 +87,7 @@ def main():
     ap.add_argument("--inflight", type=int, default=0, help="frames in flight (one context + HIP stream each); 0 = 3 on one GPU, 4 on several "
                     "(a rank's share of a frame is small: more of its latency-bound kernel chain has to overlap)")
     ap.add_argument("--batch", type=int, default=0, help="frames traced per call (rthip_render_batch_device: one set of launches for "
-                    "the rays of all of them); 0 = 8, the library's limit")
+                    "the rays of all of them); 0 = 8 on one GPU, 16 (the library's limit) on several")
     ap.add_argument("--latency", action="store_true", help="also measure the latency of ONE frame with nothing else in flight "
                     "(off by default so that every k_trace_quad launch of a default run has the same size: the rocprofv3 --stats "
                     "average of the same command is then comparable with roofline.avg_launch_ms)")
@@ -120,7 +120,9 @@ def main():
     prm = device.make_params(W, H, MAX_REC, part_index=rank, part_count=world, layout=1 if gather else 0)
 
     part_px = device.part_pixels(prm)
-    B = args.batch if args.batch > 0 else device.MAX_BATCH
+    # 8 frames per call on one GPU (8 x 2.07 M primary rays = one workspace chunk); a rank's share of a frame shrinks
+    # with the rank count, so several GPUs take the library's limit of 16
+    B = args.batch if args.batch > 0 else (8 if world == 1 else device.MAX_BATCH)
     if B > device.MAX_BATCH:
         raise SystemExit(f"--batch {B} > {device.MAX_BATCH}")
     cam_runs = {n: (device.Camera * n)(*([cam] * n)) for n in range(1, B + 1)}

@@ -20,7 +20,7 @@ SYMBOLS = ["rthip_create", "rthip_destroy", "rthip_last_error", "rthip_upload_sc
            "rthip_probe_background", "rthip_probe_raycast", "rthip_probe_arith", "rthip_version",
            "rthip_part_pixels", "rthip_assemble", "rthip_render_batch_device", "rthip_assemble_batch", "rthip_host_alloc",
            "rthip_host_free"]
-MAX_BATCH = 8  # RTHIP_MAX_BATCH
+MAX_BATCH = 16  # RTHIP_MAX_BATCH
 
 
 class Camera(C.Structure):

@@ -321,7 +321,7 @@ def test_frame_batches_are_bit_identical_to_single_frames(ctx):
         for k in range(3):
             assert np.array_equal(got[k], singles[k]), f"{parts} parts frame {k}"
     with pytest.raises(device.RthipError):
-        ctx.render_batch_device(cams + cams, prm, buf.data_ptr(), sync=True)  # 10 > RTHIP_MAX_BATCH
+        ctx.render_batch_device(cams * 4, prm, buf.data_ptr(), sync=True)  # 20 > RTHIP_MAX_BATCH
 
 
 def test_chunked_frame_batch(monkeypatch):
