@@ -192,10 +192,12 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    run_frames(max(args.warmup, F * B))  # (at least one call per context: workspaces allocated, graphs captured)
+    # warm-up: at least three calls per context of every call size the timed region uses (workspaces allocated; the
+    # library captures a frame's launch graph the second time it is asked for and replays it from the third)
+    run_frames(max(args.warmup, 3 * F * B))
     if args.steps % B:
-        for j in range(F):
-            call(j, args.steps % B)  # the shorter last call has its own captured graph on whichever context gets it
+        for j in range(3 * F):
+            call(j, args.steps % B)
     sync_all()
     t0 = time.perf_counter()
     run_frames(args.steps)

@@ -1014,6 +1014,16 @@ __device__ __forceinline__ Col resolve_chain(const Work &w, uint32_t i0, uint32_
     return c;
 }
 
+// The per-frame counters and statistics are cleared by ONE small kernel, not by hipMemsetAsync: a memset node of a
+// replayed HIP graph stopped clearing its buffer once a second graph of the same context had been instantiated
+// (ROCm 7.2; seen as garbage ray statistics), kernel nodes are not affected.
+__global__ __launch_bounds__(kBlock) void k_clear(uint32_t *a, uint32_t na, uint32_t *b, uint32_t nb, uint32_t *c, uint32_t nc) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < na) a[i] = 0u;
+    if (i < nb) b[i] = 0u;
+    if (i < nc) c[i] = 0u;
+}
+
 // chains -> pixels (Common.cpp:275-282); SSAA: result += c * (1.0f/9.0f), clamped (Raytracer.cpp:139)
 __global__ __launch_bounds__(kBlock) void k_resolve(FrameParams fp, Work w, uint32_t *pixels, int32_t *out_shape,
                                                     int32_t *out_tri) {
@@ -1147,8 +1157,12 @@ struct rthip_ctx {
     // same key comes twice in a row: a camera that moves every frame (the Sandbox preview) keeps plain launches
     // instead of paying a capture + instantiation (~1 ms) per frame.
     bool graphs_enabled = true;
-    hipGraphExec_t graph_exec = nullptr;
-    std::vector<unsigned char> graph_key;
+    struct CachedGraph {
+        std::vector<unsigned char> key;
+        hipGraphExec_t exec;
+    };
+    std::vector<CachedGraph> graphs;  // most recently captured last; at most kMaxGraphs (a caller alternating between a few frame shapes keeps them all)
+    static constexpr size_t kMaxGraphs = 4;
     std::vector<unsigned char> seen_key;  // key of the previous call: a graph is only captured for a key seen twice in a row
     uint64_t scene_generation = 0;
     int profile_launches = 0;
@@ -1203,7 +1217,7 @@ int rthip_destroy(rthip_ctx *c) {
                      &c->counts, &c->stats, &c->ids, &c->pixels_tmp, &c->ids_out, &c->bvh_nodes, &c->bvh_tris, &c->bvh_index, &c->kd_planes, &c->hits, &c->redo, &c->block_stats};
     for (DevBuf *b : all) b->release();
     for (DevBuf &b : c->probe) b.release();
-    if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
+    for (auto &g : c->graphs) (void)hipGraphExecDestroy(g.exec);
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -1522,13 +1536,15 @@ static int render_frame(rthip_ctx *c, const rthip_camera *cam, uint32_t n_frames
         put(ptrs, sizeof ptrs);
         put(&c->scene_generation, sizeof c->scene_generation);
         put(&c->count_kd, sizeof c->count_kd);
-        if (c->graph_exec && key == c->graph_key) {
+        for (const auto &g : c->graphs) {
+            if (g.key != key) continue;
             HIP_TRY(hipEventRecord(c->ev0, c->stream));
-            HIP_TRY(hipGraphLaunch(c->graph_exec, c->stream));
+            HIP_TRY(hipGraphLaunch(g.exec, c->stream));
             HIP_TRY(hipEventRecord(c->ev1, c->stream));
             c->last.pixels = (uint64_t)my_tiles * per_tile;
             c->last.launches_trace = 0;
             c->last_frames = n_frames;
+            c->seen_key = key;
             return 0;
         }
     }
@@ -1536,8 +1552,12 @@ static int render_frame(rthip_ctx *c, const rthip_camera *cam, uint32_t n_frames
     uint64_t pixels_done = 0;
     bool interrupted = false;
     auto enqueue = [&]() -> int {
-    HIP_TRY(hipMemsetAsync(w.stats, 0, sizeof(unsigned long long) * ST_COUNT, c->stream));
-    HIP_TRY(hipMemsetAsync(w.block_stats, 0, sizeof(uint2) * 2 * (size_t)c->bs_stride * levels, c->stream));
+    {
+        const uint32_t na = 2 * ST_COUNT, nb = (uint32_t)(2 * 2 * (size_t)c->bs_stride * levels);
+        const uint32_t most = na > nb ? na : nb;
+        hipLaunchKernelGGL(k_clear, dim3((most + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, (uint32_t *)w.stats, na,
+                           (uint32_t *)w.block_stats, nb, (uint32_t *)nullptr, 0u);
+    }
     auto get_event = [&](hipEvent_t *e) -> int {
         if (ev_used == c->ev_pool.size()) {
             hipEvent_t ne;
@@ -1553,7 +1573,8 @@ static int render_frame(rthip_ctx *c, const rthip_camera *cam, uint32_t n_frames
         fp.q0 = q0;
         fp.n_pix_slots = nq * per_tile;
         fp.N0 = fp.n_pix_slots * spp;
-        HIP_TRY(hipMemsetAsync(w.counts, 0, sizeof(uint32_t) * 3 * (RTHIP_MAX_RECURSION + 3), c->stream));
+        hipLaunchKernelGGL(k_clear, dim3(1), dim3(kBlock), 0, c->stream, w.counts, (uint32_t)(3 * (RTHIP_MAX_RECURSION + 3)), (uint32_t *)nullptr,
+                           0u, (uint32_t *)nullptr, 0u);
         for (uint32_t level = 0; level < levels; level++) {
             uint32_t grid = (fp.N0 + kBlock - 1) / kBlock;
             if (level > 0 && grid > kMaxGridLevel) grid = kMaxGridLevel;
@@ -1615,11 +1636,12 @@ static int render_frame(rthip_ctx *c, const rthip_camera *cam, uint32_t n_frames
     const bool capture = use_graph && key == c->seen_key;
     if (use_graph) c->seen_key = key;
     if (capture) {  // capture once, then replay
-        if (c->graph_exec) {
-            (void)hipGraphExecDestroy(c->graph_exec);
-            c->graph_exec = nullptr;
+        if (c->graphs.size() >= rthip_ctx::kMaxGraphs) {
+            (void)hipGraphExecDestroy(c->graphs.front().exec);
+            c->graphs.erase(c->graphs.begin());
         }
         hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
         hipError_t e = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal);
         int erc = 0;
         if (e == hipSuccess) {
@@ -1627,13 +1649,13 @@ static int render_frame(rthip_ctx *c, const rthip_camera *cam, uint32_t n_frames
             hipError_t e2 = hipStreamEndCapture(c->stream, &graph);
             if (e2 != hipSuccess) e = e2;
         }
-        if (e == hipSuccess && erc == 0 && graph) e = hipGraphInstantiate(&c->graph_exec, graph, nullptr, nullptr, 0);
+        if (e == hipSuccess && erc == 0 && graph) e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
         if (graph) (void)hipGraphDestroy(graph);
-        if (e == hipSuccess && erc == 0 && c->graph_exec) {
-            c->graph_key = key;
+        if (e == hipSuccess && erc == 0 && exec) {
+            c->graphs.push_back({key, exec});
             c->last_frames = n_frames;
             HIP_TRY(hipEventRecord(c->ev0, c->stream));
-            HIP_TRY(hipGraphLaunch(c->graph_exec, c->stream));
+            HIP_TRY(hipGraphLaunch(exec, c->stream));
             HIP_TRY(hipEventRecord(c->ev1, c->stream));
             c->last.pixels = pixels_done;
             c->last.launches_trace = 0;
@@ -1641,7 +1663,6 @@ static int render_frame(rthip_ctx *c, const rthip_camera *cam, uint32_t n_frames
         }
         (void)hipGetLastError();  // capture is not available here: plain launches from now on
         c->graphs_enabled = false;
-        c->graph_exec = nullptr;
         ev_used = 0;
         pixels_done = 0;
     }
