@@ -6,7 +6,8 @@ A "step" is one frame of the workload: BASELINE.json configs[2], the reference's
 MaxRecursion 3).  The flattened scene is resident in HBM before the timed
 region; every step traces the whole frame.  With N > 1 the frame is partitioned into interleaved
 32x8 screen tiles (tile t -> rank t % N), each rank renders its share into a tile-compact buffer in
-HBM, the buffers are all-gathered over RCCL and assembled into the frame on the device; total work
+HBM, the buffers are gathered to rank 0 over RCCL (--collective all_gather: to every rank) and assembled into
+the frames on the device; total work
 is fixed as N grows ("strong" scaling).
 
 Frames are traced in runs: one rthip_render_batch_device call takes --batch frames (default 8 on one GPU, 16 on several; the same camera for
@@ -91,6 +92,8 @@ def main():
     ap.add_argument("--latency", action="store_true", help="also measure the latency of ONE frame with nothing else in flight "
                     "(off by default so that every k_trace_quad launch of a default run has the same size: the rocprofv3 --stats "
                     "average of the same command is then comparable with roofline.avg_launch_ms)")
+    ap.add_argument("--collective", choices=["gather", "all_gather"], default="gather", help="framebuffer exchange: gather to rank 0 "
+                    "(each peer sends its part once) or all-gather (every rank ends up with the frames)")
     ap.add_argument("--force-gather", action="store_true", help="run the RCCL gather + assemble path even with one rank")
     args = ap.parse_args()
 
@@ -111,7 +114,7 @@ def main():
         dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29517", rank=0, world_size=1,
                                 device_id=torch.device("cuda", local_rank))
 
-    from raytracing_amd import device, host, scenes
+    from raytracing_amd import device, host, parallel, scenes
     sd, _ = scenes.config(3)
     hs = host.HostScene(sd, device_index=local_rank)
     desc = hs.flatten()
@@ -169,11 +172,12 @@ def main():
             done.record(exts[j])
             comm.wait_event(done)
             mine, gath = mines[j][:n * part_px], gathers[j][:n * part_px * world]
-            dist.all_gather_into_tensor(gath, mine)
+            complete = parallel.collect_parts(mine, gath, args.collective)
             gathered_ev = torch.cuda.Event()
             gathered_ev.record(comm)
-            exts[j].wait_event(gathered_ev)
-            c.assemble_batch(prm, n, gath.data_ptr(), frames[j].data_ptr(), sync=False)
+            exts[j].wait_event(gathered_ev)  # (every rank: its part buffer is free again only once the exchange has read it)
+            if complete:
+                c.assemble_batch(prm, n, gath.data_ptr(), frames[j].data_ptr(), sync=False)
 
     def run_frames(n_frames):
         """exactly n_frames frames: calls of B, then one shorter call for the remainder"""
@@ -243,7 +247,7 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "BASELINE configs[2]: Demo 4 bunny.obj (4968 tris, kd-tree) + checker plane + SkyBox sun, "
                                    "1920x1080, MaxRecursion 3, camera (0,0,5)", "rays_per_frame": int(rays_frame),
-                       "partition": f"interleaved 32x8 screen tiles over {world} GPU(s)" + (", RCCL all-gather + device assemble" if gather else ""),
+                       "partition": f"interleaved 32x8 screen tiles over {world} GPU(s)" + (f", RCCL {args.collective} + device assemble" if gather else ""),
                        "frames_per_call": B, "calls_in_flight": F, "single_frame_latency_ms": lat[len(lat) // 2] if lat else None,
                        "frame_checksum": checksum},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -50,3 +50,22 @@ def pixel_owner(w, h, part_count, tile_w=32, tile_h=8):
     tiles_x = -(-w // tile_w)
     ys, xs = np.mgrid[0:h, 0:w]
     return ((ys // tile_h) * tiles_x + xs // tile_w) % part_count
+
+
+def collect_parts(mine, gathered, how="gather", dst=0):
+    """The framebuffer exchange of one call (torch.distributed; RCCL on GPUs, gloo in the CPU tests): every rank
+    contributes `mine` (its tile-compact part buffers, frame after frame), `gathered` receives them rank after rank.
+    how = "gather": only rank `dst` receives (grouped send / recv: each peer sends its part once over its own xGMI
+    link; the other ranks' `gathered` stays untouched); "all_gather": every rank receives everything.
+    Returns True on the ranks whose `gathered` is complete."""
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(), dist.get_rank()
+    assert gathered.numel() == mine.numel() * world
+    if how == "all_gather":
+        dist.all_gather_into_tensor(gathered, mine)
+        return True
+    if how != "gather":
+        raise ValueError(how)
+    chunks = list(gathered.chunk(world)) if rank == dst else None
+    dist.gather(mine, chunks, dst=dst)
+    return rank == dst

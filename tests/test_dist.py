@@ -1,5 +1,6 @@
-"""CPU, world_size 2 over gloo: the multi-GPU framebuffer path (tile-compact buffers of interleaved
-screen tiles, all-gather, assemble) with the per-rank rendering done by the host-compiled core."""
+"""CPU, world_size 2 over gloo: the multi-GPU framebuffer path (tile-compact buffers of interleaved screen tiles of a
+batch of frames, parallel.collect_parts as bench.py calls it — gather to rank 0 and all-gather —, assemble) with the
+per-rank rendering done by the host-compiled core."""
 import ctypes as C
 import os
 import socket
@@ -26,19 +27,32 @@ def _worker(rank, world, port, w, h, q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     hs = host.HostScene(scenes.config(1)[0])
-    cam = hs.camera(w, h)
-    prm = device.make_params(w, h, 1)
-    px = np.zeros((h, w), np.uint32)
     HC = C.CDLL(os.path.join(ROOT, "tests", "hostcore", "libhostcore.so"))
     vp = C.c_void_p
-    HC.hc_render(vp(hs.flatten()), C.byref(cam), C.byref(prm), px.ctypes.data_as(vp), None, None, None, None, 2)
-    # this rank keeps only ITS tiles, in the tile-compact order the device writes (layout = 1)
-    mine = parallel.frame_to_part(px, rank, world)
-    gathered = [torch.zeros_like(torch.from_numpy(mine.view(np.int32))) for _ in range(world)]
-    dist.all_gather(gathered, torch.from_numpy(mine.view(np.int32)))
-    frame = parallel.assemble_parts(np.stack([g.numpy().view(np.uint32) for g in gathered]), w, h)
-    if rank == 0:
-        q.put((np.array_equal(frame, px), int((frame != px).sum())))
+    n_frames = 3  # a batch: one camera per frame
+    frames = []
+    for f in range(n_frames):
+        cam = hs.camera(w, h)
+        cam.position[0] = 0.4 * f
+        prm = device.make_params(w, h, 1)
+        px = np.zeros((h, w), np.uint32)
+        HC.hc_render(vp(hs.flatten()), C.byref(cam), C.byref(prm), px.ctypes.data_as(vp), None, None, None, None, 2)
+        frames.append(px)
+    # this rank keeps only ITS tiles of every frame, in the tile-compact order the device writes (layout = 1),
+    # frame after frame: what rthip_render_batch_device leaves in HBM
+    mine = torch.from_numpy(np.concatenate([parallel.frame_to_part(px, rank, world) for px in frames]).view(np.int32))
+    ok = True
+    for how in ("gather", "all_gather"):
+        gathered = torch.zeros(mine.numel() * world, dtype=torch.int32)
+        complete = parallel.collect_parts(mine, gathered, how)
+        assert complete == (how == "all_gather" or rank == 0)
+        if complete:  # [rank][frame][slot] -> frames: the layout rthip_assemble_batch reads
+            g = gathered.numpy().view(np.uint32).reshape(world, n_frames, -1)
+            for f in range(n_frames):
+                ok = ok and np.array_equal(parallel.assemble_parts(g[:, f], w, h), frames[f])
+        elif gathered.abs().sum().item() != 0:
+            ok = False  # a gather must leave the other ranks' buffers alone
+    q.put((rank, bool(ok)))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -50,11 +64,11 @@ def test_two_rank_gather_reassembles_the_frame():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, 200, 120, q)) for r in range(2)]
     for p in procs:
         p.start()
-    ok, bad = q.get(timeout=120)
+    results = dict(q.get(timeout=120) for _ in procs)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert ok, f"{bad} pixels differ after gather + assemble"
+    assert results == {0: True, 1: True}, "frames differ after the exchange + assemble"
 
 
 def test_partition_covers_every_pixel_exactly_once():
