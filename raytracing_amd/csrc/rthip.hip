@@ -120,6 +120,13 @@ struct __attribute__((aligned(32))) ColRec {
     double r, g, b, refl;  // direct colour (later: folded colour) and the reflectance applied to the child
 };
 static const uint32_t kNoChild = 0xffffffffu;
+// what k_trace_easy already knows about a hard ray: the closest-hit query over the ANALYTIC shapes (the reference's
+// d = |O - M*P|^2 of the winner, DBL_MAX / 0xffffffff if none), so that the quad kernel only adds the meshes
+struct __attribute__((aligned(16))) PendRec {
+    double bd;
+    uint32_t bs;
+    uint32_t pad;
+};
 struct Work {
     ColRec *rec;            // [levels][N]
     uint32_t *child;        // [levels][N]  : index of the reflected ray in level+1, kNoChild if none
@@ -132,6 +139,7 @@ struct Work {
     uint32_t *redo_count;       // [levels] one counter per level (zeroed with `counts`)
     uint32_t *hard;             // [N] rays of the current level that need a mesh walk (traced by the quad kernel)
     uint32_t *hard_count;       // [levels]
+    PendRec *pend;              // [N] per entry of the hard list
     uint2 *block_stats;         // [2][levels][bs_stride] per workgroup of k_trace_easy / k_shade: (shadow queries, reflected rays) of the frame
     uint32_t bs_stride;
     uint32_t N;
@@ -506,14 +514,15 @@ __device__ __forceinline__ void mesh_closest(const SceneView &sv, const rthip_me
 
 // Scene::CastRay (Scene.cpp:163-237) for the quad's ray; same contract as rtc::cast_ray_id.
 template <bool COUNT>
+// `known`: the query over the analytic shapes has been answered already (k_trace_easy, closest-hit query only).
 __device__ __forceinline__ int32_t cast_ray(const SceneView &sv, V3 o, V3 d, Stack qs, uint32_t q, bool any_hit, bool active,
-                                            int32_t &best_tri, bool &redo, KdCounters &cnt) {
-    double bd = DBL_MAX;
-    uint32_t bs = 0xffffffffu;
+                                            const PendRec *known, int32_t &best_tri, bool &redo, KdCounters &cnt) {
+    double bd = known ? known->bd : DBL_MAX;
+    uint32_t bs = known ? known->bs : 0xffffffffu;
     best_tri = -1;
-    bool meshes = false;
+    bool meshes = known != nullptr;  // (the quad kernel only runs on scenes with meshes)
     // analytic shapes, one per lane and pass; the earlier node wins exact distance ties (Scene.cpp:225)
-    for (uint32_t s0 = 0; s0 < sv.n_shapes; s0 += 4) {
+    for (uint32_t s0 = 0; s0 < (known ? 0u : sv.n_shapes); s0 += 4) {
         const uint32_t s = s0 + q;
         if (!active || s >= sv.n_shapes) continue;
         const rthip_shape &sh = sv.shapes[s];
@@ -536,7 +545,7 @@ __device__ __forceinline__ int32_t cast_ray(const SceneView &sv, V3 o, V3 d, Sta
         bd = distance;
         bs = s;
     }
-    reduce_min(bd, bs);
+    if (!known) reduce_min(bd, bs);
     {
         uint32_t mm = meshes ? 1u : 0u;
         mm |= dpp<kXor1>(mm);
@@ -587,8 +596,8 @@ template <bool COUNT>
 // The hit record is stored as soon as the closest query is resolved (mask 0), so that the local point and the
 // normal do not stay in registers through the shadow walks; the caller patches the shadow mask in afterwards.
 __device__ __forceinline__ bool trace_stage(const SceneView &sv, V3 o, V3 d, uint32_t n_shadow_lights, Stack qs, uint32_t q,
-                                            bool live, const Work &w, uint32_t i, int32_t &out_shape, int32_t &out_tri,
-                                            uint32_t &out_mask, KdCounters &cnt) {
+                                            bool live, const Work &w, uint32_t i, const PendRec &analytic, int32_t &out_shape,
+                                            int32_t &out_tri, uint32_t &out_mask, KdCounters &cnt) {
     bool redo = false;
     struct {
         int32_t shape, tri;
@@ -610,7 +619,7 @@ __device__ __forceinline__ bool trace_stage(const SceneView &sv, V3 o, V3 d, uin
                 rd = normalized(sub(mk(light->position[0], light->position[1], light->position[2]), point));
         }
         int32_t tri;
-        const int32_t shape = cast_ray<COUNT>(sv, ro, rd, qs, q, l >= 0, active, tri, redo, cnt);
+        const int32_t shape = cast_ray<COUNT>(sv, ro, rd, qs, q, l >= 0, active, l < 0 ? &analytic : nullptr, tri, redo, cnt);
         if (l < 0) {
             if (shape >= 0 && !redo) {
                 Hit c;
@@ -762,9 +771,10 @@ __device__ __forceinline__ bool mesh_may_hit(const SceneView &sv, const rthip_me
 
 // rtc::cast_ray_id restricted to the analytic shapes; `hard` is set when a mesh would have to be walked
 template <bool COUNT>
-__device__ __forceinline__ int32_t cast_ray(const SceneView &sv, V3 o, V3 d, bool any_hit, bool active, bool &hard, KdCounters &cnt) {
+__device__ __forceinline__ int32_t cast_ray(const SceneView &sv, V3 o, V3 d, bool any_hit, bool active, bool &hard, double &hitDistance,
+                                            KdCounters &cnt) {
     int32_t best = -1;
-    double hitDistance = DBL_MAX;
+    hitDistance = DBL_MAX;
     bool mesh_box = false;
     for (uint32_t s = 0; s < sv.n_shapes; s++) {
         const rt_uniform_shape *sh = rt_uniform_cast(sv.shapes) + s;
@@ -801,8 +811,11 @@ __device__ __forceinline__ int32_t cast_ray(const SceneView &sv, V3 o, V3 d, boo
 
 template <bool COUNT>
 __device__ __forceinline__ bool trace_stage(const SceneView &sv, V3 o, V3 d, uint32_t n_shadow_lights, bool live, HitRec &h,
-                                            KdCounters &cnt) {
+                                            PendRec &analytic, KdCounters &cnt) {
     bool hard = false;
+    analytic.bd = DBL_MAX;
+    analytic.bs = 0xffffffffu;
+    analytic.pad = 0;
     h.shape = -1;
     h.tri = -1;
     h.shadow_mask = 0;
@@ -822,8 +835,13 @@ __device__ __forceinline__ bool trace_stage(const SceneView &sv, V3 o, V3 d, uin
             else
                 rd = normalized(sub(mk(light->position[0], light->position[1], light->position[2]), point));
         }
-        const int32_t shape = cast_ray<COUNT>(sv, ro, rd, l >= 0, active, hard, cnt);
+        double distance;
+        const int32_t shape = cast_ray<COUNT>(sv, ro, rd, l >= 0, active, hard, distance, cnt);
         if (l < 0) {
+            if (shape >= 0) {
+                analytic.bd = distance;
+                analytic.bs = (uint32_t)shape;
+            }
             if (shape >= 0 && !hard) {
                 Hit c;
                 hit_details(sv, o, d, shape, -1, c, nullptr);  // an analytic shape: no triangle
@@ -869,7 +887,8 @@ __global__ __launch_bounds__(kBlock, RT_EASY_OCC) void k_trace_easy(SceneView sv
             d = mk(r.dx, r.dy, r.dz);
         }
         HitRec h;
-        const bool done = easy::trace_stage<COUNT>(sv, o, d, n_shadow, live, h, kc);
+        PendRec analytic;
+        const bool done = easy::trace_stage<COUNT>(sv, o, d, n_shadow, live, h, analytic, kc);
         // hard rays -> list (one atomic per wave); the quad kernel traces them, k_shade shades them
         const bool is_hard = live && !done;
         const unsigned long long mask = __ballot(is_hard);
@@ -878,7 +897,9 @@ __global__ __launch_bounds__(kBlock, RT_EASY_OCC) void k_trace_easy(SceneView sv
             if (lane == (uint32_t)(__ffsll((long long)mask) - 1)) wave_base = atomicAdd(&w.hard_count[0], (uint32_t)__popcll(mask));
             wave_base = __shfl(wave_base, __ffsll((long long)mask) - 1, 64);
             if (is_hard) {
-                w.hard[wave_base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = i;
+                const uint32_t slot = wave_base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+                w.hard[slot] = i;
+                w.pend[slot] = analytic;
                 if (level == 0) store_ray(w, 0, i, o, d, 0u);  // k_shade needs the direction (background, reflection)
             }
         }
@@ -926,7 +947,12 @@ __global__ __launch_bounds__(kBlock, RT_QUAD_OCC) void k_trace_quad(SceneView sv
         }
         int32_t hit_shape, hit_tri;
         uint32_t shadow_mask;
-        const bool done = quad::trace_stage<COUNT>(sv, o, d, n_shadow, qs, q, live, w, i, hit_shape, hit_tri, shadow_mask, kc);
+        PendRec analytic;
+        analytic.bd = DBL_MAX;
+        analytic.bs = 0xffffffffu;
+        analytic.pad = 0;
+        if (live) analytic = w.pend[j];
+        const bool done = quad::trace_stage<COUNT>(sv, o, d, n_shadow, qs, q, live, w, i, analytic, hit_shape, hit_tri, shadow_mask, kc);
         if (!live || q != 0) continue;
         if (COUNT && kc.nodes - nodes_before > max_ray_nodes) max_ray_nodes = kc.nodes - nodes_before;
         if (!done) {
@@ -1141,7 +1167,7 @@ struct rthip_ctx {
     bool has_scene = false;
     uint32_t stack_cap = 1;
     // frame workspace
-    DevBuf rec, child, rays, counts, stats, block_stats, ids, pixels_tmp, ids_out, hits, redo, probe[8];
+    DevBuf rec, child, rays, counts, stats, block_stats, ids, pixels_tmp, ids_out, hits, redo, pend, probe[8];
     uint32_t bs_stride = 0, bs_levels = 0;
     uint32_t n_tables = 0;
     bool has_meshes = false;
@@ -1214,7 +1240,7 @@ int rthip_destroy(rthip_ctx *c) {
     (void)hipStreamSynchronize(c->stream);
     DevBuf *all[] = {&c->shapes, &c->meshes, &c->kd_nodes, &c->kd_bounds, &c->kd_refs, &c->tris, &c->tri_normals,
                      &c->materials, &c->noises, &c->perlin, &c->worley, &c->lights, &c->rec, &c->child, &c->rays,
-                     &c->counts, &c->stats, &c->ids, &c->pixels_tmp, &c->ids_out, &c->bvh_nodes, &c->bvh_tris, &c->bvh_index, &c->kd_planes, &c->hits, &c->redo, &c->block_stats};
+                     &c->counts, &c->stats, &c->ids, &c->pixels_tmp, &c->ids_out, &c->bvh_nodes, &c->bvh_tris, &c->bvh_index, &c->kd_planes, &c->hits, &c->redo, &c->block_stats, &c->pend};
     for (DevBuf *b : all) b->release();
     for (DevBuf &b : c->probe) b.release();
     for (auto &g : c->graphs) (void)hipGraphExecDestroy(g.exec);
@@ -1489,6 +1515,7 @@ static int render_frame(rthip_ctx *c, const rthip_camera *cam, uint32_t n_frames
     if (c->ids.ensure(sizeof(int32_t) * 2 * (size_t)tiles_per_chunk * per_tile)) return RTHIP_E_HIP;
     if (c->hits.ensure(sizeof(HitSlot) * N)) return RTHIP_E_HIP;
     if (c->redo.ensure(sizeof(uint32_t) * 2 * N)) return RTHIP_E_HIP;
+    if (c->pend.ensure(sizeof(PendRec) * N)) return RTHIP_E_HIP;
     Work w;
     w.rec = (ColRec *)c->rec.p;
     w.child = (uint32_t *)c->child.p;
@@ -1500,6 +1527,7 @@ static int render_frame(rthip_ctx *c, const rthip_camera *cam, uint32_t n_frames
     w.hit = (HitSlot *)c->hits.p;
     w.redo = (uint32_t *)c->redo.p;
     w.hard = w.redo + N;
+    w.pend = (PendRec *)c->pend.p;
     w.block_stats = (uint2 *)c->block_stats.p;
     w.bs_stride = c->bs_stride;
     w.N = (uint32_t)N;
@@ -1530,7 +1558,7 @@ static int render_frame(rthip_ctx *c, const rthip_camera *cam, uint32_t n_frames
     if (use_graph) {
         auto put = [&](const void *ptr, size_t n) { key.insert(key.end(), (const unsigned char *)ptr, (const unsigned char *)ptr + n); };
         const void *ptrs[] = {d_pixels, d_shape, d_tri, c->rec.p, c->child.p, c->rays.p, c->counts.p, c->stats.p, c->block_stats.p,
-                              c->ids.p, c->hits.p, c->redo.p};
+                              c->ids.p, c->hits.p, c->redo.p, c->pend.p};
         put(cam, sizeof *cam * n_frames);
         put(p, sizeof *p);
         put(ptrs, sizeof ptrs);
