@@ -60,6 +60,9 @@ typedef struct {
      * Common.cpp:401-423): rt_lin >= ||E_3x3||_inf, rt_t >= |E translation|_inf.  They bound how far
      * the reference's self-intersection test (Scene.cpp:196-200) can reach along a shadow ray. */
     double rt_lin, rt_t;
+    /* also filled by the upload, RTHIP_SHAPE_SPHERE only: square of a radius >= sigma_max(fwd 3x3), i.e. the unit
+     * sphere lies inside the world-space ball of that radius around fwd's translation (conservative early rejection) */
+    double bound_r2;
 } rthip_shape;
 
 /* kd-tree node, 16 bytes.  Nodes of one mesh are stored in pre-order; the left child of an

@@ -778,6 +778,35 @@ inline void roundtrip_bounds(rthip_shape &sh) {
     sh.rt_t = 4.0 * tr;
     if (!(sh.rt_lin < 1e300)) sh.rt_lin = 1e300;  // NaN/inf matrices: the device then never stops early
     if (!(sh.rt_t < 1e300)) sh.rt_t = 1e300;
+    // bounding ball of a Sphere shape: |M p| <= sigma_max(M) for |p| <= 1, and sigma_max(M)^2 = lambda_max(M^T M)
+    // <= the largest absolute row sum of M^T M (exact for a rotation times a uniform scale)
+    double r2 = 0.0;
+    for (int i = 0; i < 3; i++) {
+        double row = 0.0;
+        for (int j = 0; j < 3; j++) {
+            double a = 0.0;
+            for (int k = 0; k < 3; k++) a += sh.fwd[4 * k + i] * sh.fwd[4 * k + j];
+            row += fabs(a);
+        }
+        r2 = fmax(r2, row);
+    }
+    sh.bound_r2 = r2 * (1.0 + 1e-9);
+    if (!(sh.bound_r2 < 1e300)) sh.bound_r2 = 1e300;  // NaN/inf: never rejects
+}
+
+// Early rejection of a Sphere shape in WORLD space: the unit sphere maps into the ball of squared radius r2 (above)
+// around the translation c of its transform, so a ray whose line passes outside that ball, or that starts outside
+// it and points away, cannot hit the shape.  Conservative: the margin m (1e-9 relative to the squares compared) is
+// a million times the rounding of this test and of the reference's local-space test (Scene.cpp:294-330), so every
+// ray that one accepts passes here; NaNs never reject.  Saves the world->local transform, a normalisation (square
+// root + three divisions) and the intersection for the shapes a ray is nowhere near.
+RT_HD bool sphere_ball_missed(double cx, double cy, double cz, double r2, V3 o, V3 d) {
+    V3 oc = sub(mk(cx, cy, cz), o);
+    double cc = dot(oc, oc), b = dot(oc, d), dd = dot(d, d);
+    double a = cc - r2, m = 1e-9 * (cc + r2);
+    if (!(a > m)) return false;  // the origin is inside or close to the ball
+    if (b < 0.0) return true;    // outside, heading away: both roots are negative
+    return a * dd - b * b > m * dd;
 }
 
 // Any-hit bound.  A shadow query only needs RaycastResult.Hit, but the reference decides it from the
@@ -823,6 +852,7 @@ RT_HD int32_t cast_ray_id(const SceneView &sv, V3 o, V3 d, KdStack &st, bool any
             fwd[k] = sh->fwd[k];
         }
         const int32_t type = sh->type;
+        if (type == RTHIP_SHAPE_SPHERE && sphere_ball_missed(fwd[3], fwd[7], fwd[11], sh->bound_r2, o, d)) continue;
         V3 lo = xform(inv, o, 1.0);
         V3 ld = normalized(xform(inv, d, 0.0));
         V3 p;

@@ -532,6 +532,7 @@ __device__ __forceinline__ int32_t cast_ray(const SceneView &sv, V3 o, V3 d, Sta
             continue;
         }
         if (COUNT) cnt.shapes++;
+        if (type == RTHIP_SHAPE_SPHERE && sphere_ball_missed(sh.fwd[3], sh.fwd[7], sh.fwd[11], sh.bound_r2, o, d)) continue;
         V3 lo = xform(sh.inv, o, 1.0);
         V3 ld = normalized(xform(sh.inv, d, 0.0));
         V3 p;
@@ -780,10 +781,11 @@ __device__ __forceinline__ int32_t cast_ray(const SceneView &sv, V3 o, V3 d, boo
         const rt_uniform_shape *sh = rt_uniform_cast(sv.shapes) + s;
         if (!active) continue;
         if (COUNT) cnt.shapes++;
+        const int32_t type = sh->type;
+        if (type == RTHIP_SHAPE_SPHERE && sphere_ball_missed(sh->fwd[3], sh->fwd[7], sh->fwd[11], sh->bound_r2, o, d)) continue;
         double inv[12];
 #pragma unroll
         for (int k = 0; k < 12; k++) inv[k] = sh->inv[k];
-        const int32_t type = sh->type;
         V3 lo = xform(inv, o, 1.0);
         V3 ld = normalized(xform(inv, d, 0.0));
         if (type == RTHIP_SHAPE_MESH) {
