@@ -3,10 +3,11 @@
 // Frame pipeline, per recursion level k (wavefront style; ray counts stay on the device, the host never
 // synchronises between levels):
 //   k_trace_easy     : one ray per lane.  Level 0 generates its rays.  Every query of the ray over the
-//                      analytic shapes; meshes only through a conservative test of their BVH root boxes.
-//                      Rays that cannot touch a mesh are finished AND shaded here (material / noise /
-//                      background, Lambert terms, reflected ray compacted into the level-(k+1) queue with a
-//                      wave ballot + prefix popcount and ONE atomic per workgroup); the others are listed.
+//                      analytic shapes; meshes only through a conservative test of the top two levels of
+//                      their BVH.  Rays that cannot touch a mesh are finished AND shaded here (material /
+//                      noise / background, Lambert terms, reflected ray compacted into the level-(k+1) queue
+//                      with a wave ballot + prefix popcount and ONE atomic per workgroup); the others are
+//                      listed together with their closest hit over the analytic shapes.
 //   k_trace_quad     : the listed rays, FOUR LANES PER RAY over the 4-wide BVH (namespace quad), exact fp64
 //                      triangle tests; writes hit records.
 //   k_trace<true,.>  : redo list (rays only the reference kd-tree reproduces); normally empty.
@@ -15,6 +16,8 @@
 // chain of rays (clamping Color algebra forbids a forward throughput product), 3x3 SSAA
 // sum, 0xAABBGGRR pack.  accel = 1 runs k_trace<false,.> + k_shade<false> instead (reference kd-tree,
 // one ray per lane).  No MFMA: the path is divergent fp64 VALU work.
+// A call traces 1..RTHIP_MAX_BATCH frames (one camera each) as ONE such sequence of launches: the rays of all
+// the frames share the queues.  The sequence of a repeated call is captured into a HIP graph and replayed.
 //
 // Built with -ffp-contract=off: the oracle is the non-fused x86-64 build of the reference.
 #include <hip/hip_runtime.h>
