@@ -79,3 +79,13 @@ def test_edge_case_batches_and_parts_on_the_device():
             ctx.render(cam, device.make_params(w, h, 2, part_index=p, part_count=parts), out=acc)
         assert np.array_equal(acc, single)
     ctx.close()
+
+
+@pytest.mark.parametrize("mk,w,h,kw", list(_cases()))
+def test_edge_case_oracle_matches_the_genuine_reference(oracle_lib, ref_lib, mk, w, h, kw):
+    """pins the oracle on the edge cases (skipped where oracle/_ref is absent)"""
+    sd = mk()
+    a = _oracle_frame(oracle_lib, sd, w, h, kw)
+    b = sd.build(ref_lib).render(w, h, ids=True, threads=4, **kw)
+    assert np.array_equal(a["pixels"], b["pixels"]) and np.array_equal(a["shape"], b["shape"]) and np.array_equal(a["tri"], b["tri"])
+    assert a["rays"] == b["rays"]

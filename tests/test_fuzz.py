@@ -50,3 +50,14 @@ def test_fuzz_device_matches_oracle(oracle_lib, seed):
             assert np.array_equal(got["shape"], ref["shape"]) and np.array_equal(got["tri"], ref["tri"]), f"seed {seed} kd={use_kd}: ids differ"
             assert np.array_equal(got["pixels"], ref["pixels"]), f"seed {seed} kd={use_kd} aa={aa}: {(got['pixels'] != ref['pixels']).sum()} pixels differ"
             assert got["rays"] == ref["rays"]
+
+
+@pytest.mark.parametrize("seed", FUZZ_SEEDS)
+def test_fuzz_oracle_matches_the_genuine_reference(oracle_lib, ref_lib, seed):
+    """pins the oracle itself: the C restatement and the reference compiled from its own sources (oracle/_ref,
+    skipped where that build is absent) render every random scene to the same bits"""
+    sd = random_scene(seed)
+    a = _oracle(oracle_lib, sd, 0)
+    b = sd.build(ref_lib).render(W, H, ids=True, threads=4, max_recursion=MAXREC, aa=0)
+    assert np.array_equal(a["shape"], b["shape"]) and np.array_equal(a["tri"], b["tri"])
+    assert np.array_equal(a["pixels"], b["pixels"]) and a["rays"] == b["rays"]
