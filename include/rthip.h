@@ -60,8 +60,10 @@ typedef struct {
      * Common.cpp:401-423): rt_lin >= ||E_3x3||_inf, rt_t >= |E translation|_inf.  They bound how far
      * the reference's self-intersection test (Scene.cpp:196-200) can reach along a shadow ray. */
     double rt_lin, rt_t;
-    /* also filled by the upload, RTHIP_SHAPE_SPHERE only: square of a radius >= sigma_max(fwd 3x3), i.e. the unit
-     * sphere lies inside the world-space ball of that radius around fwd's translation (conservative early rejection) */
+    /* also filled by the upload: a world-space ball that contains the shape (spheres: sigma_max(fwd 3x3) around fwd's
+     * translation; meshes: around the transformed centre of the BVH root boxes; planes: infinite), used for a
+     * conservative early rejection of rays that pass nowhere near it.  bound_r2 = squared radius. */
+    double bound_c[3];
     double bound_r2;
 } rthip_shape;
 

@@ -757,7 +757,7 @@ RT_HD bool shape_intersect(const SceneView &sv, int32_t type, int32_t mesh, V3 p
 
 // host side of the any-hit bound below (called by rthip_upload_scene)
 // E = fwd*inv - I of a shape's two 3x4 matrices (see rthip_shape.rt_lin / rt_t and anyhit_t_stop)
-inline void roundtrip_bounds(rthip_shape &sh) {
+inline void roundtrip_bounds(rthip_shape &sh, const rthip_mesh *meshes, const rthip_bvhnode *bvh_nodes) {
     double lin = 0.0, tr = 0.0;
     for (int i = 0; i < 3; i++) {
         double row = 0.0;
@@ -778,9 +778,11 @@ inline void roundtrip_bounds(rthip_shape &sh) {
     sh.rt_t = 4.0 * tr;
     if (!(sh.rt_lin < 1e300)) sh.rt_lin = 1e300;  // NaN/inf matrices: the device then never stops early
     if (!(sh.rt_t < 1e300)) sh.rt_t = 1e300;
-    // bounding ball of a Sphere shape: |M p| <= sigma_max(M) for |p| <= 1, and sigma_max(M)^2 = lambda_max(M^T M)
-    // <= the largest absolute row sum of M^T M (exact for a rotation times a uniform scale)
-    double r2 = 0.0;
+    // Bounding ball in world space.  |M p| <= sigma_max(M) |p| and sigma_max(M)^2 = lambda_max(M^T M) <= the largest
+    // absolute row sum of M^T M (exact for a rotation times a uniform scale).  Sphere: |p| <= 1 around the local
+    // origin.  Mesh: the box around the BVH root's child boxes (fp32, rounded outward by the builder), |p - centre| <=
+    // its half diagonal.  Plane: unbounded.
+    double s2 = 0.0;
     for (int i = 0; i < 3; i++) {
         double row = 0.0;
         for (int j = 0; j < 3; j++) {
@@ -788,19 +790,48 @@ inline void roundtrip_bounds(rthip_shape &sh) {
             for (int k = 0; k < 3; k++) a += sh.fwd[4 * k + i] * sh.fwd[4 * k + j];
             row += fabs(a);
         }
-        r2 = fmax(r2, row);
+        s2 = fmax(s2, row);
     }
-    sh.bound_r2 = r2 * (1.0 + 1e-9);
-    if (!(sh.bound_r2 < 1e300)) sh.bound_r2 = 1e300;  // NaN/inf: never rejects
+    double c[3] = {0.0, 0.0, 0.0}, rad2 = 1.0;
+    if (sh.type == RTHIP_SHAPE_MESH) {
+        rad2 = 0.0;
+        const rthip_mesh &m = meshes[sh.mesh];
+        if (m.bvh_node_count) {
+            const rthip_bvhnode &root = bvh_nodes[m.bvh_node_base];
+            double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+            for (int k = 0; k < 4; k++) {
+                if (root.c[k].child == RTHIP_BVH_ABSENT) continue;
+                for (int a = 0; a < 3; a++) {
+                    lo[a] = fmin(lo[a], (double)root.c[k].lo[a]);
+                    hi[a] = fmax(hi[a], (double)root.c[k].hi[a]);
+                }
+            }
+            if (lo[0] <= hi[0]) {
+                for (int a = 0; a < 3; a++) {
+                    c[a] = 0.5 * (lo[a] + hi[a]);
+                    const double h = 0.5 * (hi[a] - lo[a]);
+                    rad2 += h * h;
+                }
+                rad2 *= 1.0 + 1e-6;
+            }
+        }
+    }
+    for (int i = 0; i < 3; i++) sh.bound_c[i] = sh.fwd[4 * i] * c[0] + sh.fwd[4 * i + 1] * c[1] + sh.fwd[4 * i + 2] * c[2] + sh.fwd[4 * i + 3];
+    sh.bound_r2 = s2 * rad2 * (1.0 + 1e-9);
+    const bool finite = sh.bound_r2 < 1e300 && fabs(sh.bound_c[0]) < 1e300 && fabs(sh.bound_c[1]) < 1e300 && fabs(sh.bound_c[2]) < 1e300;
+    if (sh.type == RTHIP_SHAPE_PLANE || !finite) {  // unbounded, or NaN/inf matrices: never rejects
+        sh.bound_c[0] = sh.bound_c[1] = sh.bound_c[2] = 0.0;
+        sh.bound_r2 = 1e300;
+    }
 }
 
-// Early rejection of a Sphere shape in WORLD space: the unit sphere maps into the ball of squared radius r2 (above)
-// around the translation c of its transform, so a ray whose line passes outside that ball, or that starts outside
-// it and points away, cannot hit the shape.  Conservative: the margin m (1e-9 relative to the squares compared) is
+// Early rejection of a Sphere or Mesh shape in WORLD space: the shape lies inside the ball of squared radius r2
+// around c (above), so a ray whose line passes outside that ball, or that starts outside it and points away,
+// cannot hit the shape.  Conservative: the margin m (1e-9 relative to the squares compared) is
 // a million times the rounding of this test and of the reference's local-space test (Scene.cpp:294-330), so every
 // ray that one accepts passes here; NaNs never reject.  Saves the world->local transform, a normalisation (square
-// root + three divisions) and the intersection for the shapes a ray is nowhere near.
-RT_HD bool sphere_ball_missed(double cx, double cy, double cz, double r2, V3 o, V3 d) {
+// root + three divisions) and the intersection / the BVH root tests for the shapes a ray is nowhere near.
+RT_HD bool ball_missed(double cx, double cy, double cz, double r2, V3 o, V3 d) {
     V3 oc = sub(mk(cx, cy, cz), o);
     double cc = dot(oc, oc), b = dot(oc, d), dd = dot(d, d);
     double a = cc - r2, m = 1e-9 * (cc + r2);
@@ -852,7 +883,7 @@ RT_HD int32_t cast_ray_id(const SceneView &sv, V3 o, V3 d, KdStack &st, bool any
             fwd[k] = sh->fwd[k];
         }
         const int32_t type = sh->type;
-        if (type == RTHIP_SHAPE_SPHERE && sphere_ball_missed(fwd[3], fwd[7], fwd[11], sh->bound_r2, o, d)) continue;
+        if (type != RTHIP_SHAPE_PLANE && ball_missed(sh->bound_c[0], sh->bound_c[1], sh->bound_c[2], sh->bound_r2, o, d)) continue;
         V3 lo = xform(inv, o, 1.0);
         V3 ld = normalized(xform(inv, d, 0.0));
         V3 p;

@@ -535,7 +535,7 @@ __device__ __forceinline__ int32_t cast_ray(const SceneView &sv, V3 o, V3 d, Sta
             continue;
         }
         if (COUNT) cnt.shapes++;
-        if (type == RTHIP_SHAPE_SPHERE && sphere_ball_missed(sh.fwd[3], sh.fwd[7], sh.fwd[11], sh.bound_r2, o, d)) continue;
+        if (type == RTHIP_SHAPE_SPHERE && ball_missed(sh.bound_c[0], sh.bound_c[1], sh.bound_c[2], sh.bound_r2, o, d)) continue;
         V3 lo = xform(sh.inv, o, 1.0);
         V3 ld = normalized(xform(sh.inv, d, 0.0));
         V3 p;
@@ -563,6 +563,7 @@ __device__ __forceinline__ int32_t cast_ray(const SceneView &sv, V3 o, V3 d, Sta
         if (sh->type != RTHIP_SHAPE_MESH) continue;
         if (!active || redo || (any_hit && bs != 0xffffffffu)) continue;
         if (COUNT) cnt.shapes += (q == 0);
+        if (ball_missed(sh->bound_c[0], sh->bound_c[1], sh->bound_c[2], sh->bound_r2, o, d)) continue;
         double inv[12], fwd[12];
 #pragma unroll
         for (int k = 0; k < 12; k++) {
@@ -785,7 +786,7 @@ __device__ __forceinline__ int32_t cast_ray(const SceneView &sv, V3 o, V3 d, boo
         if (!active) continue;
         if (COUNT) cnt.shapes++;
         const int32_t type = sh->type;
-        if (type == RTHIP_SHAPE_SPHERE && sphere_ball_missed(sh->fwd[3], sh->fwd[7], sh->fwd[11], sh->bound_r2, o, d)) continue;
+        if (type != RTHIP_SHAPE_PLANE && ball_missed(sh->bound_c[0], sh->bound_c[1], sh->bound_c[2], sh->bound_r2, o, d)) continue;
         double inv[12];
 #pragma unroll
         for (int k = 0; k < 12; k++) inv[k] = sh->inv[k];
@@ -1398,7 +1399,7 @@ int rthip_upload_scene(rthip_ctx *c, const rthip_scene_desc *s) {
     c->has_scene = false;
     HIP_TRY(hipStreamSynchronize(c->stream));
     std::vector<rthip_shape> shapes(s->shapes, s->shapes + s->n_shapes);
-    for (rthip_shape &sh : shapes) roundtrip_bounds(sh);
+    for (rthip_shape &sh : shapes) roundtrip_bounds(sh, s->meshes, s->bvh_nodes);
     if ((rc = upload(c, c->shapes, shapes.data(), sizeof(rthip_shape) * s->n_shapes))) return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));  // `shapes` is a local
     if ((rc = upload(c, c->meshes, s->meshes, sizeof(rthip_mesh) * s->n_meshes))) return rc;

@@ -17,7 +17,7 @@ static std::vector<rthip_shape> g_shapes;  // with the round-trip bounds rthip_u
 static SceneView view_of(const rthip_scene_desc *s) {
     SceneView v;
     g_shapes.assign(s->shapes, s->shapes + s->n_shapes);
-    for (rthip_shape &sh : g_shapes) roundtrip_bounds(sh);
+    for (rthip_shape &sh : g_shapes) roundtrip_bounds(sh, s->meshes, s->bvh_nodes);
     v.shapes = g_shapes.data(); v.n_shapes = s->n_shapes; v.meshes = s->meshes;
     v.kd_nodes = s->kd_nodes; v.kd_bounds = s->kd_bounds; v.kd_refs = s->kd_refs; v.kd_planes = s->kd_planes;
     v.tris = s->tris; v.tri_normals = s->tri_normals; v.bvh_nodes = s->bvh_nodes; v.bvh_tris = s->bvh_tris;
