@@ -273,6 +273,12 @@ const char *rthip_last_error(void);
 /* replaces: the pointer-linked scene the reference walks per ray (Scene.cpp:168-237, 469-493);
  * called once per frame after Scene::Compile (Raytracer.cpp:42) */
 int rthip_upload_scene(rthip_ctx *ctx, const rthip_scene_desc *scene);
+/* The same for a scene whose MESH GEOMETRY is the one already uploaded: everything is replaced except the mesh
+ * arrays (kd_*, tris, tri_normals, bvh_*), whose pointers in `scene` are ignored (may be null); their counts and
+ * the meshes[] table must equal the uploaded ones.  A frame-after-frame caller that only moves nodes, lights,
+ * materials or the camera (the Sandbox preview) does not ship hundreds of MB per frame.
+ * replaces: Mesh::Compile returning early when nothing was invalidated (Scene.cpp:386-388) */
+int rthip_update_scene(rthip_ctx *ctx, const rthip_scene_desc *scene);
 
 /* replaces: the per-pixel loop of AbstractRaycaster::DoRaytraceThread + ColorsToPixels
  * (Raytracer.cpp:123-170) for the Raycast of re::Raytracer (Raytracer.cpp:187-315).

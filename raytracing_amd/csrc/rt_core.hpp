@@ -757,7 +757,8 @@ RT_HD bool shape_intersect(const SceneView &sv, int32_t type, int32_t mesh, V3 p
 
 // host side of the any-hit bound below (called by rthip_upload_scene)
 // E = fwd*inv - I of a shape's two 3x4 matrices (see rthip_shape.rt_lin / rt_t and anyhit_t_stop)
-inline void roundtrip_bounds(rthip_shape &sh, const rthip_mesh *meshes, const rthip_bvhnode *bvh_nodes) {
+// mesh_roots: the BVH root node of every mesh (meshes[] order; unused for meshes without a BVH)
+inline void roundtrip_bounds(rthip_shape &sh, const rthip_mesh *meshes, const rthip_bvhnode *mesh_roots) {
     double lin = 0.0, tr = 0.0;
     for (int i = 0; i < 3; i++) {
         double row = 0.0;
@@ -797,7 +798,7 @@ inline void roundtrip_bounds(rthip_shape &sh, const rthip_mesh *meshes, const rt
         rad2 = 0.0;
         const rthip_mesh &m = meshes[sh.mesh];
         if (m.bvh_node_count) {
-            const rthip_bvhnode &root = bvh_nodes[m.bvh_node_base];
+            const rthip_bvhnode &root = mesh_roots[sh.mesh];
             double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
             for (int k = 0; k < 4; k++) {
                 if (root.c[k].child == RTHIP_BVH_ABSENT) continue;

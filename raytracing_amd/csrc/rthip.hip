@@ -1171,6 +1171,9 @@ struct rthip_ctx {
     DevBuf shapes, meshes, kd_nodes, kd_bounds, kd_refs, tris, tri_normals, materials, noises, perlin, worley, lights;
     SceneView sv;
     bool has_scene = false;
+    rthip_scene_desc uploaded{};             // the last uploaded description (its counts; the pointers are the caller's)
+    std::vector<rthip_mesh> mesh_table;      // host copies for rthip_update_scene
+    std::vector<rthip_bvhnode> mesh_roots;
     uint32_t stack_cap = 1;
     // frame workspace
     DevBuf rec, child, rays, counts, stats, block_stats, ids, pixels_tmp, ids_out, hits, redo, pend, probe[8];
@@ -1277,7 +1280,8 @@ int rthip_get_stats(rthip_ctx *c, rthip_stats *out) {
 }
 
 // ---------------------------------------------------------------------------- scene upload
-static int validate_scene(const rthip_scene_desc *s, uint32_t *max_depth, uint32_t *max_bvh_depth) {
+// keep_geometry: the mesh arrays are the ones already on the device (rthip_update_scene): only their counts are used
+static int validate_scene(const rthip_scene_desc *s, uint32_t *max_depth, uint32_t *max_bvh_depth, bool keep_geometry) {
 #define BAD(...) return fail(RTHIP_E_INVALID, "rthip_upload_scene: " __VA_ARGS__)
     if (s->n_shapes && !s->shapes) BAD("shapes is null");
     if (s->n_lights && !s->lights) BAD("lights is null");
@@ -1285,11 +1289,12 @@ static int validate_scene(const rthip_scene_desc *s, uint32_t *max_depth, uint32
     if (s->n_noises && !s->noises) BAD("noises is null");
     // (a mesh without triangles is legal: Mesh::Compile builds a one-leaf kd-tree over nothing and no BVH)
     if (s->n_meshes && !s->meshes) BAD("meshes is null");
-    if (s->n_kd_nodes && (!s->kd_nodes || !s->kd_bounds)) BAD("kd node arrays are null");
-    if (s->n_kd_refs && !s->kd_refs) BAD("kd_refs is null");
-    if (s->n_tris && (!s->tris || !s->tri_normals)) BAD("triangle arrays are null");
-    if (s->n_bvh_nodes && (!s->bvh_nodes || !s->bvh_tris || !s->bvh_tri_index)) BAD("bvh arrays are null");
-    if (s->n_kd_refs && !s->kd_refs) BAD("kd_refs is null");
+    if (!keep_geometry) {
+        if (s->n_kd_nodes && (!s->kd_nodes || !s->kd_bounds)) BAD("kd node arrays are null");
+        if (s->n_kd_refs && !s->kd_refs) BAD("kd_refs is null");
+        if (s->n_tris && (!s->tris || !s->tri_normals)) BAD("triangle arrays are null");
+        if (s->n_bvh_nodes && (!s->bvh_nodes || !s->bvh_tris || !s->bvh_tri_index)) BAD("bvh arrays are null");
+    }
     if (s->n_perlin_tables && !s->perlin_tables) BAD("perlin_tables is null");
     if (s->n_worley_points && !s->worley_points) BAD("worley_points is null");
     *max_depth = 0;
@@ -1328,6 +1333,8 @@ static int validate_scene(const rthip_scene_desc *s, uint32_t *max_depth, uint32
         if ((uint64_t)m.tri_base + m.tri_count > s->n_tris) BAD("mesh %u: triangles out of range", i);
         if (m.max_depth > RTHIP_KD_MAX_DEPTH) BAD("mesh %u: max_depth %u", i, m.max_depth);
         if (m.max_depth > *max_depth) *max_depth = m.max_depth;
+        if (m.bvh_depth > *max_bvh_depth) *max_bvh_depth = m.bvh_depth;
+        if (keep_geometry) continue;  // (the table itself is compared with the uploaded one by the caller)
         for (uint32_t k = 0; k < m.node_count; k++) {
             const rthip_kdnode &nd = s->kd_nodes[m.node_base + k];
             if (nd.info & RTHIP_KD_LEAF) {
@@ -1390,28 +1397,53 @@ static int upload(rthip_ctx *c, DevBuf &b, const void *src, size_t bytes) {
     return 0;
 }
 
+static int upload_scene(rthip_ctx *c, const rthip_scene_desc *s, bool keep_geometry);
+
 int rthip_upload_scene(rthip_ctx *c, const rthip_scene_desc *s) {
     if (!c || !s) return fail(RTHIP_E_INVALID, "rthip_upload_scene: null argument");
+    return upload_scene(c, s, false);
+}
+
+int rthip_update_scene(rthip_ctx *c, const rthip_scene_desc *s) {
+    if (!c || !s) return fail(RTHIP_E_INVALID, "rthip_update_scene: null argument");
+    if (!c->has_scene) return fail(RTHIP_E_STATE, "rthip_update_scene: no scene uploaded");
+    const rthip_scene_desc &u = c->uploaded;
+    if (s->n_meshes != u.n_meshes || s->n_kd_nodes != u.n_kd_nodes || s->n_kd_refs != u.n_kd_refs || s->n_kd_planes != u.n_kd_planes ||
+        s->n_tris != u.n_tris || s->n_bvh_nodes != u.n_bvh_nodes || (s->n_meshes && !s->meshes) ||
+        (s->n_meshes && memcmp(s->meshes, c->mesh_table.data(), sizeof(rthip_mesh) * s->n_meshes) != 0))
+        return fail(RTHIP_E_INVALID, "rthip_update_scene: the mesh table / geometry counts differ from the uploaded scene");
+    return upload_scene(c, s, true);
+}
+
+static int upload_scene(rthip_ctx *c, const rthip_scene_desc *s, bool keep_geometry) {
     uint32_t max_depth = 0, max_bvh_depth = 0;
-    int rc = validate_scene(s, &max_depth, &max_bvh_depth);
+    int rc = validate_scene(s, &max_depth, &max_bvh_depth, keep_geometry);
     if (rc) return rc;
     if (set_device(c)) return RTHIP_E_HIP;
     c->has_scene = false;
     HIP_TRY(hipStreamSynchronize(c->stream));
+    if (!keep_geometry) {  // host copies of what an update needs later: the mesh table and every mesh's BVH root
+        c->mesh_table.assign(s->meshes, s->meshes + s->n_meshes);
+        c->mesh_roots.assign(s->n_meshes, rthip_bvhnode{});
+        for (uint32_t i = 0; i < s->n_meshes; i++)
+            if (s->meshes[i].bvh_node_count) c->mesh_roots[i] = s->bvh_nodes[s->meshes[i].bvh_node_base];
+    }
     std::vector<rthip_shape> shapes(s->shapes, s->shapes + s->n_shapes);
-    for (rthip_shape &sh : shapes) roundtrip_bounds(sh, s->meshes, s->bvh_nodes);
+    for (rthip_shape &sh : shapes) roundtrip_bounds(sh, c->mesh_table.data(), c->mesh_roots.data());
     if ((rc = upload(c, c->shapes, shapes.data(), sizeof(rthip_shape) * s->n_shapes))) return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));  // `shapes` is a local
-    if ((rc = upload(c, c->meshes, s->meshes, sizeof(rthip_mesh) * s->n_meshes))) return rc;
-    if ((rc = upload(c, c->kd_nodes, s->kd_nodes, sizeof(rthip_kdnode) * s->n_kd_nodes))) return rc;
-    if ((rc = upload(c, c->kd_bounds, s->kd_bounds, sizeof(double) * 6 * s->n_kd_nodes))) return rc;
-    if ((rc = upload(c, c->kd_refs, s->kd_refs, sizeof(uint32_t) * s->n_kd_refs))) return rc;
-    if ((rc = upload(c, c->tris, s->tris, sizeof(rthip_tri) * s->n_tris))) return rc;
-    if ((rc = upload(c, c->tri_normals, s->tri_normals, sizeof(double) * 9 * s->n_tris))) return rc;
-    if ((rc = upload(c, c->kd_planes, s->kd_planes, sizeof(double) * s->n_kd_planes))) return rc;
-    if ((rc = upload(c, c->bvh_nodes, s->bvh_nodes, sizeof(rthip_bvhnode) * s->n_bvh_nodes))) return rc;
-    if ((rc = upload(c, c->bvh_tris, s->bvh_tris, s->n_bvh_nodes ? sizeof(rthip_tri) * s->n_tris : 0))) return rc;
-    if ((rc = upload(c, c->bvh_index, s->bvh_tri_index, s->n_bvh_nodes ? sizeof(uint32_t) * s->n_tris : 0))) return rc;
+    if (!keep_geometry) {
+        if ((rc = upload(c, c->meshes, s->meshes, sizeof(rthip_mesh) * s->n_meshes))) return rc;
+        if ((rc = upload(c, c->kd_nodes, s->kd_nodes, sizeof(rthip_kdnode) * s->n_kd_nodes))) return rc;
+        if ((rc = upload(c, c->kd_bounds, s->kd_bounds, sizeof(double) * 6 * s->n_kd_nodes))) return rc;
+        if ((rc = upload(c, c->kd_refs, s->kd_refs, sizeof(uint32_t) * s->n_kd_refs))) return rc;
+        if ((rc = upload(c, c->tris, s->tris, sizeof(rthip_tri) * s->n_tris))) return rc;
+        if ((rc = upload(c, c->tri_normals, s->tri_normals, sizeof(double) * 9 * s->n_tris))) return rc;
+        if ((rc = upload(c, c->kd_planes, s->kd_planes, sizeof(double) * s->n_kd_planes))) return rc;
+        if ((rc = upload(c, c->bvh_nodes, s->bvh_nodes, sizeof(rthip_bvhnode) * s->n_bvh_nodes))) return rc;
+        if ((rc = upload(c, c->bvh_tris, s->bvh_tris, s->n_bvh_nodes ? sizeof(rthip_tri) * s->n_tris : 0))) return rc;
+        if ((rc = upload(c, c->bvh_index, s->bvh_tri_index, s->n_bvh_nodes ? sizeof(uint32_t) * s->n_tris : 0))) return rc;
+    }
     if ((rc = upload(c, c->materials, s->materials, sizeof(rthip_matop) * s->n_materials))) return rc;
     if ((rc = upload(c, c->noises, s->noises, sizeof(rthip_noise) * s->n_noises))) return rc;
     if ((rc = upload(c, c->perlin, s->perlin_tables, (size_t)256 * s->n_perlin_tables))) return rc;
@@ -1446,6 +1478,7 @@ int rthip_upload_scene(rthip_ctx *c, const rthip_scene_desc *s) {
     c->stack_cap_bvh = 3 * max_bvh_depth + 2;  // one ray per lane over the 4-wide BVH: up to three pending children per level
     c->stack_cap_full = (max_depth + 2 > c->stack_cap_bvh ? max_depth + 2 : c->stack_cap_bvh);  // degenerate rays walk the kd-tree
     c->stack_cap = c->stack_cap_full;
+    c->uploaded = *s;  // counts only are read later (rthip_update_scene)
     c->has_scene = true;
     c->scene_generation++;
     return 0;

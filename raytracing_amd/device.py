@@ -19,7 +19,7 @@ SYMBOLS = ["rthip_create", "rthip_destroy", "rthip_last_error", "rthip_upload_sc
            "rthip_get_stats", "rthip_probe_cast", "rthip_probe_noise", "rthip_probe_material",
            "rthip_probe_background", "rthip_probe_raycast", "rthip_probe_arith", "rthip_version",
            "rthip_part_pixels", "rthip_assemble", "rthip_render_batch_device", "rthip_assemble_batch", "rthip_host_alloc",
-           "rthip_host_free"]
+           "rthip_host_free", "rthip_update_scene"]
 MAX_BATCH = 16  # RTHIP_MAX_BATCH
 
 
@@ -77,6 +77,7 @@ def lib():
     L.rthip_last_error.restype = C.c_char_p
     L.rthip_version.restype = C.c_char_p
     L.rthip_upload_scene.argtypes = [vp, vp]
+    L.rthip_update_scene.argtypes = [vp, vp]
     L.rthip_render.argtypes = [vp, C.POINTER(Camera), C.POINTER(Params), c_u32p, c_i32p, c_i32p]
     L.rthip_render_device.argtypes = [vp, C.POINTER(Camera), C.POINTER(Params), vp, C.c_int]
     L.rthip_part_pixels.argtypes = [C.POINTER(Params)]
@@ -142,6 +143,10 @@ class Context:
     def upload(self, desc_ptr):
         """desc_ptr: `const rthip_scene_desc*` (e.g. from host.HostScene.flatten())."""
         self._check(self.L.rthip_upload_scene(self.h, desc_ptr))
+
+    def update(self, desc_ptr):
+        """like upload() for a scene whose mesh geometry is the one already uploaded (rthip_update_scene)"""
+        self._check(self.L.rthip_update_scene(self.h, desc_ptr))
 
     def render(self, cam, params, ids=False, out=None):
         n = params.width * params.height

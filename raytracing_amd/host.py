@@ -40,6 +40,7 @@ def load_host():
         L.rehost_scenes_xml.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_char_p, C.c_int]
         L.rehost_load_obj.argtypes = [C.c_char_p, C.c_char_p, C.c_void_p, C.c_void_p, C.c_int]
         L.rehost_write_ppm.argtypes = [C.c_char_p, C.c_void_p, C.c_int, C.c_int]
+        L.rehost_render_moved.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.POINTER(C.c_int)]
         _host = sb
     return _host
 
@@ -90,6 +91,19 @@ class HostScene:
             return self.built.render(*a, **kw)
         except RuntimeError as e:
             raise RuntimeError(str(e) + ": " + self.L.rehost_last_error().decode())
+
+    def render_moved(self, width, height, dx, max_recursion=3):
+        """Two frames through ONE HipRaytracer; between them every node under the root moves by dx along x and the
+        camera by dx / 2.  Returns (pixels of the second frame, whether it kept the device geometry).  The scene stays
+        moved, so a later render() shows what a fresh renderer makes of it."""
+        from .sbapi import RenderParams
+        p = RenderParams(width, height, 0.0, max_recursion, 0, 8, 0)
+        px = np.zeros((height, width), np.uint32)
+        kept = C.c_int(0)
+        rc = self.L.rehost_render_moved(self.h, C.byref(p), C.c_double(dx), px.ctypes.data_as(C.c_void_p), C.byref(kept))
+        if rc != 0:
+            raise RuntimeError(f"rehost_render_moved failed ({rc}): " + self.L.rehost_last_error().decode())
+        return px, bool(kept.value)
 
     def last_stats(self):
         out = (C.c_double * 8)()

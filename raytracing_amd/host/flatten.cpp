@@ -15,6 +15,8 @@
 namespace re {
 namespace {
 
+constexpr int kGeometryChanged = 1;  // internal: the meshes are not the ones of `previous`
+
 struct Flattener {
     Scene *scene;
     FlatScene &out;
@@ -23,6 +25,7 @@ struct Flattener {
     std::map<const Noise *, int32_t> noise_index;
     std::map<const Perlin *, int32_t> table_index;
     std::map<const Mesh *, int32_t> mesh_index;
+    const FlatScene *previous;  // non-null: keep its geometry (see FlattenScene)
 
     int Unsupported(const std::string &what) {
         error = what;
@@ -131,6 +134,16 @@ struct Flattener {
     int AddMesh(const Mesh *mesh, int32_t &idx) {
         auto it = mesh_index.find(mesh);
         if (it != mesh_index.end()) { idx = it->second; return 0; }
+        if (previous) {  // the next mesh must be the one `previous` has at this position, unchanged
+            const size_t k = out.meshes.size();
+            if (k >= previous->mesh_signature.size() || previous->mesh_signature[k] != std::make_pair(mesh, mesh->GetRevision()))
+                return kGeometryChanged;
+            idx = (int32_t)k;
+            out.meshes.push_back(previous->meshes[k]);
+            out.mesh_signature.push_back(previous->mesh_signature[k]);
+            mesh_index[mesh] = idx;
+            return 0;
+        }
         const KdTreeFlat &kd = mesh->GetKdTree();
         const auto &tris = mesh->GetTriangles();
         if (kd.nodes.empty()) return Unsupported("Mesh was not compiled");
@@ -211,6 +224,7 @@ struct Flattener {
         });
         idx = (int32_t)out.meshes.size();
         out.meshes.push_back(m);
+        out.mesh_signature.emplace_back(mesh, mesh->GetRevision());
         mesh_index[mesh] = idx;
         return 0;
     }
@@ -314,17 +328,48 @@ struct Flattener {
         d.perlin_tables = out.perlin_tables.data(); d.n_perlin_tables = (uint32_t)(out.perlin_tables.size() / 256);
         d.worley_points = out.worley_points.data(); d.n_worley_points = out.worley_points.size() / 3;
         d.lights = out.lights.data();               d.n_lights = (uint32_t)out.lights.size();
+        if (previous) {
+            if (out.meshes.size() != previous->meshes.size()) return kGeometryChanged;
+            out.geometry_kept = true;
+            const rthip_scene_desc &pd = previous->desc;
+            d.kd_nodes = nullptr; d.kd_bounds = nullptr; d.kd_refs = nullptr; d.kd_planes = nullptr; d.tris = nullptr;
+            d.tri_normals = nullptr; d.bvh_nodes = nullptr; d.bvh_tris = nullptr; d.bvh_tri_index = nullptr;
+            d.n_kd_nodes = pd.n_kd_nodes; d.n_kd_refs = pd.n_kd_refs; d.n_kd_planes = pd.n_kd_planes; d.n_tris = pd.n_tris;
+            d.n_bvh_nodes = pd.n_bvh_nodes;
+        }
         return 0;
     }
 };
 
 }  // namespace
 
-int FlattenScene(Scene *scene, FlatScene &out, std::string &error) {
+int FlattenScene(Scene *scene, FlatScene &out, std::string &error, const FlatScene *previous) {
+    if (previous) {
+        out = FlatScene();
+        std::memset(&out.desc, 0, sizeof out.desc);
+        Flattener f{scene, out, error, {}, {}, {}, {}, previous};
+        const int rc = f.Run();
+        if (rc != kGeometryChanged) return rc;
+    }
     out = FlatScene();
     std::memset(&out.desc, 0, sizeof out.desc);
-    Flattener f{scene, out, error, {}, {}, {}, {}};
+    Flattener f{scene, out, error, {}, {}, {}, {}, nullptr};
     return f.Run();
+}
+
+void FlatScene::ReleaseGeometry() {
+    std::vector<rthip_kdnode>().swap(kd_nodes);
+    std::vector<double>().swap(kd_bounds);
+    std::vector<uint32_t>().swap(kd_refs);
+    std::vector<double>().swap(kd_planes);
+    std::vector<rthip_tri>().swap(tris);
+    std::vector<double>().swap(tri_normals);
+    std::vector<rthip_bvhnode>().swap(bvh_nodes);
+    std::vector<rthip_tri>().swap(bvh_tris);
+    std::vector<uint32_t>().swap(bvh_tri_index);
+    rthip_scene_desc &d = desc;  // counts stay: they describe what the device holds
+    d.kd_nodes = nullptr; d.kd_bounds = nullptr; d.kd_refs = nullptr; d.kd_planes = nullptr; d.tris = nullptr;
+    d.tri_normals = nullptr; d.bvh_nodes = nullptr; d.bvh_tris = nullptr; d.bvh_tri_index = nullptr;
 }
 
 void MakeCamera(const Scene *scene, size_t width, size_t height, real fovY, rthip_camera &cam) {

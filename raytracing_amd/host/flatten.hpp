@@ -28,11 +28,20 @@ struct FlatScene {
     std::vector<rthip_light> lights;
     rthip_scene_desc desc;
     std::vector<SceneNode *> shape_nodes;  // pre-order shape ordinal -> node
+    // (mesh, Mesh::GetRevision()) in meshes[] order: identifies the geometry arrays above
+    std::vector<std::pair<const Mesh *, uint64_t>> mesh_signature;
+    bool geometry_kept = false;  // flattened against `previous`: geometry arrays empty, desc pointers null, counts kept
+
+    // drops the geometry arrays (they can be hundreds of MB) but keeps what a later FlattenScene(..., this) needs
+    void ReleaseGeometry();
 };
 
 // Returns 0 or RTHIP_E_UNSUPPORTED (user-defined Shape/Material/Noise/Background subclass, nesting
 // too deep, ...) with a message in `error`.  The scene must have been compiled.
-int FlattenScene(Scene *scene, FlatScene &out, std::string &error);
+// previous != nullptr: if the scene's meshes are exactly the ones `previous` was flattened from (same objects, same
+// revisions, same order) only the small tables are rebuilt (shapes / transforms, materials, noises, lights,
+// background); the mesh table is copied and the geometry arrays are left out for rthip_update_scene.
+int FlattenScene(Scene *scene, FlatScene &out, std::string &error, const FlatScene *previous = nullptr);
 
 // Camera basis of AbstractRaycaster::CreateScreenRay (Raytracer.cpp:102-110) computed once per frame.
 void MakeCamera(const Scene *scene, size_t width, size_t height, real fovY, rthip_camera &cam);

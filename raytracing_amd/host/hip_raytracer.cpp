@@ -108,8 +108,10 @@ void HipRaytracer::RenderThread(Scene *scene, std::promise<RenderStatus> p) {
     try {
         auto t0 = clock::now();
         scene->Compile();  // Raytracer.cpp:42
+        // m_Flat describes what the device holds (geometry arrays released): if the meshes are still the same objects
+        // at the same revision, only the small tables are flattened and uploaded again
         FlatScene flat;
-        rc = FlattenScene(scene, flat, err);
+        rc = FlattenScene(scene, flat, err, m_Ctx ? m_Flat.get() : nullptr);
         auto t1 = clock::now();
         stats.FlattenMs = ms(t0, t1);
         if (!rc) {
@@ -120,8 +122,15 @@ void HipRaytracer::RenderThread(Scene *scene, std::promise<RenderStatus> p) {
             }
         }
         if (!rc) {
-            rc = rthip_upload_scene(m_Ctx, &flat.desc);
+            rc = flat.geometry_kept ? rthip_update_scene(m_Ctx, &flat.desc) : rthip_upload_scene(m_Ctx, &flat.desc);
             if (rc) err = rthip_last_error();
+            if (!rc) {
+                stats.GeometryKept = flat.geometry_kept;
+                flat.ReleaseGeometry();
+                m_Flat.reset(new FlatScene(std::move(flat)));
+            } else {
+                m_Flat.reset();  // the device scene is in an unknown state: full upload next time
+            }
         }
         auto t2 = clock::now();
         stats.UploadMs = ms(t1, t2);

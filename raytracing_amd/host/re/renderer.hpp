@@ -7,6 +7,7 @@
 #include <atomic>
 #include <condition_variable>
 #include <future>
+#include <memory>
 #include <mutex>
 #include <stdexcept>
 #include <string>
@@ -60,11 +61,14 @@ public:
     int Code;
 };
 
+struct FlatScene;  // flatten.hpp
+
 struct HipRenderStats {
     unsigned long long RaysPrimary = 0, RaysShadow = 0, RaysReflect = 0, Pixels = 0;
     float DeviceMs = 0.f;     // HIP-event time of the frame's kernels
     float FlattenMs = 0.f;    // host: Scene::Compile + flatten
     float UploadMs = 0.f;     // host->device scene upload
+    bool GeometryKept = false;  // the meshes were the ones already on the device: only the small tables went up
 };
 
 class HipRaytracer : public AbstractRaycaster {  // drop-in for re::Raytracer (Raytracer.h:100-116)
@@ -91,6 +95,7 @@ private:
     void RenderThread(Scene *scene, std::promise<RenderStatus> p);
     rthip_ctx *m_Ctx = nullptr;
     bool m_PixelsPinned = false;
+    std::unique_ptr<FlatScene> m_Flat;  // the scene as last uploaded, geometry arrays released (see RenderThread)
     int m_CreateRc = 0;
     std::string m_CreateErr;
     std::mutex m_Mutex;

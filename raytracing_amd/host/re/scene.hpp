@@ -230,8 +230,12 @@ public:
     const KdTreeFlat &GetKdTree() const { return m_KdTree; }                    // additive
     const BvhFlat &GetBvh() const { return m_Bvh; }                             // additive
     const BoundingBox &GetBounds() const { return m_BoundingBox; }              // additive
+    // additive: changes every time Compile() rebuilds the acceleration structures (process-wide unique), so a renderer
+    // can tell that the geometry it has already flattened and uploaded is still the current one
+    uint64_t GetRevision() const { return m_Revision; }
 private:
     bool m_Invalidated = true;
+    uint64_t m_Revision = 0;
     KdTreeFlat m_KdTree;
     BvhFlat m_Bvh;
     std::vector<Triangle> m_Triangles;

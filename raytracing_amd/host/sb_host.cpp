@@ -353,6 +353,35 @@ int sb_render(sb_scene *s, const sb_render_params *p, uint32_t *pixels, int32_t 
     }
 }
 
+// Two frames through ONE renderer, as the Sandbox preview does frame after frame (Sandbox.cpp:359): after the first
+// frame every node directly under the root is moved by dx along x and the camera by dx / 2; the second frame and
+// whether it kept the device geometry (HipRenderStats::GeometryKept) are returned.  The scene stays moved.
+int rehost_render_moved(sb_scene *s, const sb_render_params *p, double dx, uint32_t *pixels_second, int *geometry_kept) {
+    try {
+        real fovy = p->fovy > 0 ? p->fovy : PI / 4;
+        HipRaytracer rt(p->width, p->height, fovy);
+        rt.MaxRecursion = p->max_recursion;
+        rt.Device = s->device;
+        rt.UseReferenceKdTree = s->use_kd != 0;
+        rt.RenderSync(s->scene.get());
+        for (auto &child : s->scene->GetRoot()->GetChildren()) child->GetComponentOfType<Transform>()->Position.X += dx;
+        s->scene->Camera.Position.X += dx / 2;
+        unsigned int *px = rt.RenderSync(s->scene.get());
+        std::memcpy(pixels_second, px, sizeof(uint32_t) * (size_t)p->width * p->height);
+        *geometry_kept = rt.GetLastStats().GeometryKept ? 1 : 0;
+        s->last_stats = rt.GetLastStats();
+        s->compiled = false;
+        s->uploaded = false;
+        return 0;
+    } catch (const DeviceError &e) {
+        g_host_err = e.what();
+        return e.Code;
+    } catch (const std::exception &e) {
+        g_host_err = e.what();
+        return RTHIP_E_INVALID;
+    }
+}
+
 // ---- asynchronous contract of Renderer::Render / GetStatus / Interrupt (Raytracer.h:36-43) ----
 struct rehost_job {
     std::unique_ptr<HipRaytracer> rt;

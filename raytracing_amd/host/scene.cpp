@@ -2,6 +2,7 @@
 // caches (Scene.cpp:509-523) and the kd-tree with the reference's splitting rules
 // (Scene.cpp:18-95), emitted directly in the flat pre-order layout the device walks.
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -455,6 +456,8 @@ void Mesh::Compile() {
     auto T2 = std::chrono::steady_clock::now();
     if (getenv("RE_BUILD_TIMING")) fprintf(stderr, "Mesh::Compile %zu tris: kd %.3f s, bvh %.3f s\n", m_Triangles.size(), std::chrono::duration<double>(T1 - T0).count(), std::chrono::duration<double>(T2 - T1).count());
     m_Invalidated = false;
+    static std::atomic<uint64_t> revisions{0};
+    m_Revision = ++revisions;
 }
 
 }  // namespace re

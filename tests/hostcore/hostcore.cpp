@@ -17,7 +17,10 @@ static std::vector<rthip_shape> g_shapes;  // with the round-trip bounds rthip_u
 static SceneView view_of(const rthip_scene_desc *s) {
     SceneView v;
     g_shapes.assign(s->shapes, s->shapes + s->n_shapes);
-    for (rthip_shape &sh : g_shapes) roundtrip_bounds(sh, s->meshes, s->bvh_nodes);
+    std::vector<rthip_bvhnode> roots(s->n_meshes);
+    for (uint32_t i = 0; i < s->n_meshes; i++)
+        if (s->meshes[i].bvh_node_count) roots[i] = s->bvh_nodes[s->meshes[i].bvh_node_base];
+    for (rthip_shape &sh : g_shapes) roundtrip_bounds(sh, s->meshes, roots.data());
     v.shapes = g_shapes.data(); v.n_shapes = s->n_shapes; v.meshes = s->meshes;
     v.kd_nodes = s->kd_nodes; v.kd_bounds = s->kd_bounds; v.kd_refs = s->kd_refs; v.kd_planes = s->kd_planes;
     v.tris = s->tris; v.tri_normals = s->tri_normals; v.bvh_nodes = s->bvh_nodes; v.bvh_tris = s->bvh_tris;

@@ -368,6 +368,34 @@ def test_full_size_properties_config3(ctx):
     assert int((a["tri"] >= 0).sum()) == int((a["shape"] == 1).sum()) > 100000
 
 
+def test_repeated_renders_keep_the_device_geometry():
+    """HipRaytracer renders frame after frame (the Sandbox preview): when only nodes / the camera moved, the second
+    frame re-uploads the small tables and keeps the mesh geometry on the device (rthip_update_scene); the image must
+    be the one a fresh renderer makes of the moved scene."""
+    for mk in (lambda: scenes.config(3, cam_z=2.5)[0], lambda: scenes.config(5, cells=24)[0], lambda: scenes.config(2)[0]):
+        hs = host.HostScene(mk())
+        second, kept = hs.render_moved(200, 112, 0.35, max_recursion=3)
+        assert kept, "the second frame shipped the geometry again"
+        fresh = hs.render(200, 112, max_recursion=3)["pixels"]
+        assert np.array_equal(second, fresh)
+        again, kept = hs.render_moved(200, 112, -0.2, max_recursion=3)   # a new renderer: first frame full, second kept
+        assert kept and np.array_equal(again, hs.render(200, 112, max_recursion=3)["pixels"])
+        assert not np.array_equal(again, second)
+
+
+def test_update_scene_rejects_other_geometry(ctx):
+    big = host.HostScene(scenes.config(3)[0])
+    small = host.HostScene(scenes.config(4, cells=8)[0])
+    ctx.upload(big.flatten())
+    with pytest.raises(device.RthipError):
+        ctx.update(small.flatten())          # another mesh table
+    ctx.update(big.flatten())                # the same scene again: fine (pointers are ignored)
+    w, h = 96, 54
+    a = ctx.render(big.camera(w, h), device.make_params(w, h, 2))["pixels"].copy()
+    ctx.upload(big.flatten())
+    assert np.array_equal(a, ctx.render(big.camera(w, h), device.make_params(w, h, 2))["pixels"])
+
+
 def test_render_contract_async_status_interrupt():
     """AbstractRaycaster::Render contract (Raytracer.cpp:34-99): returns at once, status pollable, promise
     satisfied exactly once with Finished = true — also after Interrupt()."""
