@@ -54,6 +54,16 @@ def measured_traffic(launches):
     return t.get("k_trace_quad_bytes_per_launch")
 
 
+def measured_valu():
+    """VALU issue utilisation / waiting fraction of the dominant kernel from the committed PMC passes of config 3
+    (profiles/r01_pmc_summary_config3.json, tools/prof_passes.sh + prof_summary.py): what actually bounds it."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_summary_config3.json")
+    if not os.path.exists(path):
+        return None
+    k = json.load(open(path))["kernels"].get("k_trace_quad<false>")
+    return None if k is None else {"valu_issue_util": k["valu_issue_util"], "wave_time_waiting": k["wave_time_waiting"], "l2_hit_rate": k["l2_hit_rate"]}
+
+
 def cpu_baseline(sd, max_seconds=25.0):
     """Times the CPU renderer on the host cores on a bounded sample of the same workload."""
     import oracle
@@ -255,8 +265,10 @@ def main():
                          "kernel": "k_trace_quad", "launches_per_call": int(st.launches_trace), "avg_launch_ms": launch_ms,
                          "algorithmic_bytes_per_call_rank0": int(abytes), "rays_traced_by_kernel_per_call_rank0": int(cst.rays_hard),
                          "frames_per_call": B,
-                         "note": "the flattened bunny BVH (~0.8 MB) is L2-resident: the kernel is bound by the dependent-step "
-                                 "latency of its slowest wave, not by HBM; see DESIGN.md"},
+                         "pmc": measured_valu(),
+                         "note": "the flattened bunny BVH (~0.8 MB) is L2-resident, so the algorithmic bytes are served by L2 (HBM traffic per "
+                                 "launch is `traffic`, ~25x less) and frac ~ 1 of the HBM peak does not mean HBM-bound: the kernel is bound by fp64 "
+                                 "VALU issue and dependent-step latency (`pmc`); see DESIGN.md"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sd)

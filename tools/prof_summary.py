@@ -15,6 +15,8 @@ for f in glob.glob(d + "/*/**/*counter_collection.csv", recursive=True):
 print(f"PMC summary of `{d}` ({frames} frames; rocprofv3 --pmc, one pass per counter group, MI355X)\n")
 print("| kernel | launches/frame | waves/frame | VALU instr/frame (M) | VALU issue util. of the SIMDs | wave time in s_waitcnt | issue-stalled | L2 hit rate | HBM/MALL read MB/frame | GPU ms/frame |")
 print("|---|---|---|---|---|---|---|---|---|---|")
+import json
+summary = {}
 for k, c in sorted(acc.items()):
     if not k.startswith("k_") or c.get("SQ_WAVES", 0) == 0:
         continue
@@ -27,5 +29,9 @@ for k, c in sorted(acc.items()):
     print(f"| `{k}` | {calls[k] / frames:.0f} | {c['SQ_WAVES'] / frames:,.0f} | {c['SQ_INSTS_VALU'] / frames / 1e6:.1f} | {100 * valu_util:.0f} % | "
           f"{100 * c['SQ_WAIT_ANY'] / wc:.0f} % | {100 * c['SQ_WAIT_INST_ANY'] / wc:.0f} % | {100 * c.get('TCC_HIT_sum', 0) / req if req else 0:.0f} % | "
           f"{c.get('TCC_EA0_RDREQ_sum', 0) * 128 / frames / 1e6:.1f} | {ms:.3f} |")
+    summary[k] = {"valu_issue_util": valu_util, "wave_time_waiting": c["SQ_WAIT_ANY"] / wc, "l2_hit_rate": c.get("TCC_HIT_sum", 0) / req if req else None,
+                  "valu_instructions_per_frame": c["SQ_INSTS_VALU"] / frames, "gpu_ms_per_frame_serialised": ms}
+if len(sys.argv) > 3:  # machine-readable copy (bench.py quotes the dominant kernel's VALU figures from it)
+    json.dump({"source": d, "frames": frames, "kernels": summary}, open(sys.argv[3], "w"), indent=1)
 print("\nVALU issue utilisation = 4 cycles x SQ_ACTIVE_INST_VALU / (1024 SIMDs x kernel cycles); HBM/MALL read = TCC_EA0_RDREQ x 128 B "
       "(gfx950 tallies 128-byte requests, MI355X_MICROARCH.md); GPU ms from GRBM_GUI_ACTIVE at 2.4 GHz (PMC runs serialise kernels).")
