@@ -659,14 +659,21 @@ __device__ __forceinline__ bool trace_stage(const SceneView &sv, V3 o, V3 d, uin
 // compacted into the next level's queue: wave ballot + prefix popcount, the four waves of a workgroup
 // combined through LDS so that ONE returning atomic per workgroup reserves the queue range.
 // `have`: this lane holds a traced ray (index i in the level, hit record h, direction d).
+// HARD (k_trace_easy): the same reservation step also appends the workgroup's hard rays to the hard list - with one
+// atomic per WAVE, a 4K frame whose rays mostly need the mesh sent 130 K returning atomics to one address per level,
+// ~0.7 ms of serialisation in L2.
 struct ShadeShared {
     uint32_t wave_cnt[kBlock / 64];
     uint32_t block_base;
+    uint32_t hard_cnt[kBlock / 64];
+    uint32_t hard_base;
     uint32_t part[2][kBlock / 64];
 };
+template <bool HARD>
 __device__ __forceinline__ void shade_and_spawn(const SceneView &sv, const FrameParams &fp, const Work &w, const uint8_t *tabs,
                                                 ShadeShared &sh, uint32_t level, bool have, uint32_t i, const HitRec &h, V3 d,
-                                                uint32_t &shadow_total, uint32_t &spawn_total) {
+                                                uint32_t &shadow_total, uint32_t &spawn_total, bool is_hard = false,
+                                                const PendRec *analytic = nullptr, V3 o = V3{0, 0, 0}) {
     const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
     ShadeOut so;
     so.spawn = false;
@@ -683,13 +690,28 @@ __device__ __forceinline__ void shade_and_spawn(const SceneView &sv, const Frame
         rec_at(w, level, i) = cr;
     }
     const unsigned long long mask = __ballot(so.spawn);
-    if (lane == 0) sh.wave_cnt[wid] = (uint32_t)__popcll(mask);
+    const unsigned long long hmask = HARD ? __ballot(is_hard) : 0ull;
+    if (lane == 0) {
+        sh.wave_cnt[wid] = (uint32_t)__popcll(mask);
+        if (HARD) sh.hard_cnt[wid] = (uint32_t)__popcll(hmask);
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
         uint32_t total = sh.wave_cnt[0] + sh.wave_cnt[1] + sh.wave_cnt[2] + sh.wave_cnt[3];
         sh.block_base = total ? atomicAdd(&w.counts[level + 1], total) : 0u;
     }
+    if (HARD && threadIdx.x == 64) {  // (another wave: the two atomics are in flight together)
+        uint32_t total = sh.hard_cnt[0] + sh.hard_cnt[1] + sh.hard_cnt[2] + sh.hard_cnt[3];
+        sh.hard_base = total ? atomicAdd(&w.hard_count[0], total) : 0u;
+    }
     __syncthreads();
+    if (HARD && is_hard) {  // listed for the quad kernel (which traces it) and k_shade (which shades it)
+        uint32_t slot = sh.hard_base + (uint32_t)__popcll(hmask & ((1ull << lane) - 1ull));
+        for (uint32_t k = 0; k < wid; k++) slot += sh.hard_cnt[k];
+        w.hard[slot] = i;
+        w.pend[slot] = *analytic;
+        if (level == 0) store_ray(w, 0, i, o, d, 0u);  // k_shade needs the direction (background, reflection)
+    }
     uint32_t child = kNoChild;
     if (so.spawn) {
         uint32_t j = sh.block_base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
@@ -895,25 +917,12 @@ __global__ __launch_bounds__(kBlock, RT_EASY_OCC) void k_trace_easy(SceneView sv
         HitRec h;
         PendRec analytic;
         const bool done = easy::trace_stage<COUNT>(sv, o, d, n_shadow, live, h, analytic, kc);
-        // hard rays -> list (one atomic per wave); the quad kernel traces them, k_shade shades them
-        const bool is_hard = live && !done;
-        const unsigned long long mask = __ballot(is_hard);
-        if (mask) {
-            uint32_t wave_base = 0;
-            if (lane == (uint32_t)(__ffsll((long long)mask) - 1)) wave_base = atomicAdd(&w.hard_count[0], (uint32_t)__popcll(mask));
-            wave_base = __shfl(wave_base, __ffsll((long long)mask) - 1, 64);
-            if (is_hard) {
-                const uint32_t slot = wave_base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-                w.hard[slot] = i;
-                w.pend[slot] = analytic;
-                if (level == 0) store_ray(w, 0, i, o, d, 0u);  // k_shade needs the direction (background, reflection)
-            }
-        }
+        const bool is_hard = live && !done;  // -> hard list, in shade_and_spawn's reservation step
         if (live && done && level == 0 && w.id_shape && i / fp.n_pix_slots == (fp.aa ? 4u : 0u)) {
             w.id_shape[pix_slot] = h.shape;
             w.id_tri[pix_slot] = -1;
         }
-        shade_and_spawn(sv, fp, w, tabs, sh, level, live && done, i, h, d, shadow_total, spawn_total);
+        shade_and_spawn<true>(sv, fp, w, tabs, sh, level, live && done, i, h, d, shadow_total, spawn_total, is_hard, &analytic, o);
     }
     shade_stats_flush(w, sh, 0, level, levels, shadow_total, spawn_total);
     if (COUNT) {
@@ -1016,7 +1025,7 @@ __global__ __launch_bounds__(kBlock, RT_SHADE_OCC) void k_shade(SceneView sv, Fr
             const RayRec rr = ray_at(w, level, i);
             d = mk(rr.dx, rr.dy, rr.dz);
         }
-        shade_and_spawn(sv, fp, w, tabs, sh, level, hs.shape > -2, i, h, d, shadow_total, spawn_total);
+        shade_and_spawn<false>(sv, fp, w, tabs, sh, level, hs.shape > -2, i, h, d, shadow_total, spawn_total);
     }
     shade_stats_flush(w, sh, 1, level, levels, shadow_total, spawn_total);
 }
