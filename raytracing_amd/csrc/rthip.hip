@@ -123,6 +123,11 @@ struct __attribute__((aligned(32))) ColRec {
     double r, g, b, refl;  // direct colour (later: folded colour) and the reflectance applied to the child
 };
 static const uint32_t kNoChild = 0xffffffffu;
+// Every device counter that workgroups reserve list space from (rays of a level, hard list, redo list) sits in a
+// 256-byte line of its own: returning atomics to ONE line serialise in L2 (~7 ns each), and the spawn and hard-list
+// reservations of a workgroup are in flight together.
+static const uint32_t kCounterStride = 64;  // in uint32
+static const uint32_t kCounterSlots = 3 * (RTHIP_MAX_RECURSION + 3);
 // what k_trace_easy already knows about a hard ray: the closest-hit query over the ANALYTIC shapes (the reference's
 // d = |O - M*P|^2 of the winner, DBL_MAX / 0xffffffff if none), so that the quad kernel only adds the meshes
 struct __attribute__((aligned(16))) PendRec {
@@ -134,7 +139,7 @@ struct Work {
     ColRec *rec;            // [levels][N]
     uint32_t *child;        // [levels][N]  : index of the reflected ray in level+1, kNoChild if none
     RayRec *rays;           // [2][N]       : ping-pong ray queues
-    uint32_t *counts;       // [levels+1]   : rays per level
+    uint32_t *counts;       // [levels+1] x kCounterStride : rays per level (see level_count)
     unsigned long long *stats;  // [ST_COUNT]
     int32_t *id_shape, *id_tri; // [n_pix_slots] primary-hit ids (optional)
     HitSlot *hit;               // [N] per ray of the current level
@@ -148,6 +153,7 @@ struct Work {
     uint32_t N;
 };
 
+__device__ __forceinline__ uint32_t &level_count(const Work &w, uint32_t level) { return w.counts[(size_t)level * kCounterStride]; }
 __device__ __forceinline__ ColRec &rec_at(const Work &w, uint32_t level, uint32_t i) { return w.rec[(size_t)level * w.N + i]; }
 __device__ __forceinline__ RayRec &ray_at(const Work &w, uint32_t level, uint32_t i) { return w.rays[(size_t)(level & 1) * w.N + i]; }
 __device__ __forceinline__ void store_ray(const Work &w, uint32_t level, uint32_t i, V3 o, V3 d, uint32_t parent) {
@@ -277,7 +283,7 @@ __global__ __launch_bounds__(kBlock, RT_TRACE_OCC) void k_trace(SceneView sv, Fr
                                                                  uint32_t stack_cap) {
     // LDS: stack_cap child words per lane (no entry parameters: nothing is culled on a pop here)
     KdStack st = make_stack(lds_dyn + threadIdx.x, kBlock, stack_cap, nullptr);
-    const uint32_t n = REDO ? w.redo_count[0] : ((level == 0) ? fp.N0 : w.counts[level]);
+    const uint32_t n = REDO ? w.redo_count[0] : ((level == 0) ? fp.N0 : level_count(w, level));
     const uint32_t n_shadow = fp.renderer == RTHIP_RENDER_RAYTRACER ? sv.n_lights : 0u;  // DebugRaycaster: closest hit only
     KdCounters kc = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t max_ray_nodes = 0;
@@ -698,7 +704,7 @@ __device__ __forceinline__ void shade_and_spawn(const SceneView &sv, const Frame
     __syncthreads();
     if (threadIdx.x == 0) {
         uint32_t total = sh.wave_cnt[0] + sh.wave_cnt[1] + sh.wave_cnt[2] + sh.wave_cnt[3];
-        sh.block_base = total ? atomicAdd(&w.counts[level + 1], total) : 0u;
+        sh.block_base = total ? atomicAdd(&level_count(w, level + 1), total) : 0u;
     }
     if (HARD && threadIdx.x == 64) {  // (another wave: the two atomics are in flight together)
         uint32_t total = sh.hard_cnt[0] + sh.hard_cnt[1] + sh.hard_cnt[2] + sh.hard_cnt[3];
@@ -892,7 +898,7 @@ template <bool COUNT>
 __global__ __launch_bounds__(kBlock, RT_EASY_OCC) void k_trace_easy(SceneView sv, FrameParams fp, Work w, uint32_t level,
                                                                       uint32_t n_tables, uint32_t levels) {
     __shared__ ShadeShared sh;
-    const uint32_t n = (level == 0) ? fp.N0 : w.counts[level];
+    const uint32_t n = (level == 0) ? fp.N0 : level_count(w, level);
     if (blockIdx.x * kBlock >= n) return;
     const uint8_t *tabs = reinterpret_cast<const uint8_t *>(lds_dyn);
     stage_perlin_tables(sv, n_tables);
@@ -1000,7 +1006,7 @@ template <bool LIST>
 __global__ __launch_bounds__(kBlock, RT_SHADE_OCC) void k_shade(SceneView sv, FrameParams fp, Work w, uint32_t level, uint32_t n_tables,
                                                                  uint32_t levels) {
     __shared__ ShadeShared sh;
-    const uint32_t n = LIST ? w.hard_count[0] : ((level == 0) ? fp.N0 : w.counts[level]);
+    const uint32_t n = LIST ? w.hard_count[0] : ((level == 0) ? fp.N0 : level_count(w, level));
     if (blockIdx.x * kBlock >= n) return;
     const uint8_t *tabs = reinterpret_cast<const uint8_t *>(lds_dyn);
     stage_perlin_tables(sv, n_tables);
@@ -1555,7 +1561,7 @@ static int render_frame(rthip_ctx *c, const rthip_camera *cam, uint32_t n_frames
     if (c->rec.ensure(sizeof(ColRec) * N * levels)) return RTHIP_E_HIP;
     if (c->child.ensure(sizeof(uint32_t) * N * levels)) return RTHIP_E_HIP;
     if (c->rays.ensure(sizeof(RayRec) * 2 * N)) return RTHIP_E_HIP;
-    if (c->counts.ensure(sizeof(uint32_t) * 3 * (RTHIP_MAX_RECURSION + 3))) return RTHIP_E_HIP;
+    if (c->counts.ensure(sizeof(uint32_t) * kCounterSlots * kCounterStride)) return RTHIP_E_HIP;
     if (c->stats.ensure(sizeof(unsigned long long) * ST_COUNT)) return RTHIP_E_HIP;
     c->bs_stride = (uint32_t)((N + kBlock - 1) / kBlock);
     c->bs_levels = levels;
@@ -1649,8 +1655,8 @@ static int render_frame(rthip_ctx *c, const rthip_camera *cam, uint32_t n_frames
         fp.q0 = q0;
         fp.n_pix_slots = nq * per_tile;
         fp.N0 = fp.n_pix_slots * spp;
-        hipLaunchKernelGGL(k_clear, dim3(1), dim3(kBlock), 0, c->stream, w.counts, (uint32_t)(3 * (RTHIP_MAX_RECURSION + 3)), (uint32_t *)nullptr,
-                           0u, (uint32_t *)nullptr, 0u);
+        hipLaunchKernelGGL(k_clear, dim3((kCounterSlots * kCounterStride + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, w.counts,
+                           kCounterSlots * kCounterStride, (uint32_t *)nullptr, 0u, (uint32_t *)nullptr, 0u);
         for (uint32_t level = 0; level < levels; level++) {
             uint32_t grid = (fp.N0 + kBlock - 1) / kBlock;
             if (level > 0 && grid > kMaxGridLevel) grid = kMaxGridLevel;
@@ -1659,8 +1665,8 @@ static int render_frame(rthip_ctx *c, const rthip_camera *cam, uint32_t n_frames
                 if (get_event(&ea) || get_event(&eq) || get_event(&eb) || get_event(&ec)) return RTHIP_E_HIP;
                 HIP_TRY(hipEventRecord(ea, c->stream));
             }
-            w.redo_count = w.counts + (RTHIP_MAX_RECURSION + 3) + level;
-            w.hard_count = w.counts + 2 * (RTHIP_MAX_RECURSION + 3) + level;
+            w.redo_count = w.counts + (size_t)((RTHIP_MAX_RECURSION + 3) + level) * kCounterStride;
+            w.hard_count = w.counts + (size_t)(2 * (RTHIP_MAX_RECURSION + 3) + level) * kCounterStride;
             if (p->accel == 0) {
                 if (c->count_kd)
                     hipLaunchKernelGGL((k_trace_easy<true>), dim3(grid), dim3(kBlock), lds_tables, c->stream, c->sv, fp, w, level, c->n_tables, levels);
@@ -1798,17 +1804,15 @@ static int finish_stats(rthip_ctx *c, const rthip_params *p) {
     c->last.fetch_cycles = st[ST_FETCH_CYCLES];
     c->last.shape_tests_easy = st[ST_SHAPES_EASY];
     {
-        uint32_t hc[RTHIP_MAX_RECURSION + 1];
-        HIP_TRY(hipMemcpy(hc, (const uint32_t *)c->counts.p + 2 * (RTHIP_MAX_RECURSION + 3), sizeof hc, hipMemcpyDeviceToHost));
+        std::vector<uint32_t> all(kCounterSlots * kCounterStride);
+        HIP_TRY(hipMemcpy(all.data(), c->counts.p, sizeof(uint32_t) * all.size(), hipMemcpyDeviceToHost));
         uint64_t hard = 0;
-        for (uint32_t i = 0; i <= p->max_recursion && i <= RTHIP_MAX_RECURSION; i++) hard += hc[i];
+        for (uint32_t i = 0; i <= p->max_recursion && i <= RTHIP_MAX_RECURSION; i++) hard += all[(size_t)(2 * (RTHIP_MAX_RECURSION + 3) + i) * kCounterStride];
+        for (uint32_t i = 0; i <= RTHIP_MAX_RECURSION; i++) c->last.level_rays[i] = i <= p->max_recursion ? all[(size_t)i * kCounterStride] : 0;
         c->last.rays_hard = p->accel == 0 ? hard : 0;  // last chunk only (frames of <= 2^24 rays per level are one chunk)
     }
-    uint32_t lr[RTHIP_MAX_RECURSION + 1];
-    HIP_TRY(hipMemcpy(lr, c->counts.p, sizeof lr, hipMemcpyDeviceToHost));
     memset(c->last.level_ms_trace, 0, sizeof c->last.level_ms_trace);
     memset(c->last.level_ms_shade, 0, sizeof c->last.level_ms_shade);
-    for (uint32_t i = 0; i <= RTHIP_MAX_RECURSION; i++) c->last.level_rays[i] = i <= p->max_recursion ? lr[i] : 0;
     c->last.level_rays[0] = (uint32_t)c->last.rays_primary;
     c->last.ms_total = ms;
     float sum = 0.f, sum_easy = 0.f;
