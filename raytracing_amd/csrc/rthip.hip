@@ -85,7 +85,7 @@ static const uint32_t kBlock = 256;           // 4 waves per workgroup
 #ifndef RT_SHADE_OCC
 #define RT_SHADE_OCC 4
 #endif
-static const uint32_t kMaxGridQuad = 16384;    // same for the quad kernel (64 rays per workgroup)
+static const uint32_t kMaxGridQuad = 8192;     // quad kernel (64 rays per workgroup, grid-stride): 16384 costs 2 % when calls overlap, 4096 3 % on a lone 4K frame
 static const size_t kMaxLevelRays = (size_t)1 << 24;  // level-0 rays per chunk (bounds the workspace); RTHIP_CHUNK_RAYS overrides (tests)
 static const uint32_t kMaxGridLevel = 4096;   // queue levels: grid-stride over a bounded grid
 enum { ST_KD_NODES = 0, ST_KD_TRIS, ST_KD_LEAVES, ST_KD_POPS, ST_SHAPES, ST_MESH_HITS, ST_KD_MAXRAY, ST_WAVE_STEPS_MAX, ST_WAVE_TRIS_MAX, ST_WAVE_STEPS, ST_WAVE_TRIS, ST_WAVE_CYCLES_MAX, ST_FETCH_CYCLES, ST_SHAPES_EASY, ST_COUNT };
