@@ -87,7 +87,8 @@ static const uint32_t kBlock = 256;           // 4 waves per workgroup
 #endif
 static const uint32_t kMaxGridQuad = 8192;     // quad kernel (64 rays per workgroup, grid-stride): 16384 costs 2 % when calls overlap, 4096 3 % on a lone 4K frame
 static const size_t kMaxLevelRays = (size_t)1 << 24;  // level-0 rays per chunk (bounds the workspace); RTHIP_CHUNK_RAYS overrides (tests)
-static const uint32_t kMaxGridLevel = 4096;   // queue levels: grid-stride over a bounded grid
+static const uint32_t kMaxGridLevel = 4096;   // k_trace_easy / k_shade / k_trace: grid-stride over a bounded grid (one workgroup per 256 rays
+                                              // costs 6 % when calls overlap: LDS table staging, statistics flush and launch per workgroup)
 enum { ST_KD_NODES = 0, ST_KD_TRIS, ST_KD_LEAVES, ST_KD_POPS, ST_SHAPES, ST_MESH_HITS, ST_KD_MAXRAY, ST_WAVE_STEPS_MAX, ST_WAVE_TRIS_MAX, ST_WAVE_STEPS, ST_WAVE_TRIS, ST_WAVE_CYCLES_MAX, ST_FETCH_CYCLES, ST_SHAPES_EASY, ST_COUNT };
 
 // Per-frame constants
@@ -1659,7 +1660,7 @@ static int render_frame(rthip_ctx *c, const rthip_camera *cam, uint32_t n_frames
                            kCounterSlots * kCounterStride, (uint32_t *)nullptr, 0u, (uint32_t *)nullptr, 0u);
         for (uint32_t level = 0; level < levels; level++) {
             uint32_t grid = (fp.N0 + kBlock - 1) / kBlock;
-            if (level > 0 && grid > kMaxGridLevel) grid = kMaxGridLevel;
+            if (grid > kMaxGridLevel) grid = kMaxGridLevel;  // every level: the kernels stride over their rays (see kMaxGridLevel)
             hipEvent_t ea = nullptr, eq = nullptr, eb = nullptr, ec = nullptr;
             if (c->profile_launches) {
                 if (get_event(&ea) || get_event(&eq) || get_event(&eb) || get_event(&ec)) return RTHIP_E_HIP;
