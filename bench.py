@@ -55,13 +55,15 @@ def measured_traffic(launches):
 
 
 def measured_valu():
-    """VALU issue utilisation / waiting fraction of the dominant kernel from the committed PMC passes of config 3
-    (profiles/r01_pmc_summary_config3.json, tools/prof_passes.sh + prof_summary.py): what actually bounds it."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_summary_config3.json")
+    """VALU issue utilisation / waiting fraction of the dominant kernel from the committed PMC passes over the
+    bench's own shape of work, 8-frame calls of config 3 (profiles/r01_pmc_summary_config3_batch8.json,
+    `tools/prof_passes.sh <tag> 3 4 8` + prof_summary.py): what actually bounds it."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_summary_config3_batch8.json")
     if not os.path.exists(path):
         return None
     k = json.load(open(path))["kernels"].get("k_trace_quad<false>")
-    return None if k is None else {"valu_issue_util": k["valu_issue_util"], "wave_time_waiting": k["wave_time_waiting"], "l2_hit_rate": k["l2_hit_rate"]}
+    return None if k is None else {"valu_issue_util": k["valu_issue_util"], "wave_time_waiting": k["wave_time_waiting"], "l2_hit_rate": k["l2_hit_rate"],
+                                   "source": "profiles/r01_pmc_summary_config3_batch8.json"}
 
 
 def cpu_baseline(sd, max_seconds=25.0):
@@ -267,8 +269,9 @@ def main():
                          "frames_per_call": B,
                          "pmc": measured_valu(),
                          "note": "the flattened bunny BVH (~0.8 MB) is L2-resident, so the algorithmic bytes are served by L2 (HBM traffic per "
-                                 "launch is `traffic`, ~25x less) and frac ~ 1 of the HBM peak does not mean HBM-bound: the kernel is bound by fp64 "
-                                 "VALU issue and dependent-step latency (`pmc`); see DESIGN.md"},
+                                 "launch is `traffic`, ~25x less) and frac ~ 1 of the HBM peak does not mean HBM-bound: the kernel is bound by VALU "
+                                 "issue (`pmc`: the SIMDs issue VALU instructions 2/3 of the time on this workload, and are issue-stalled most of "
+                                 "the rest); see DESIGN.md"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sd)
