@@ -1243,7 +1243,7 @@ int rthip_create(int device, rthip_ctx **out) {
     if (e == hipSuccess) e = hipEventCreate(&c->ev0);
     if (e == hipSuccess) e = hipEventCreate(&c->ev1);
     if (e != hipSuccess) {
-        delete c;
+        rthip_destroy(c);  // releases whichever of the three exist
         return fail(RTHIP_E_HIP, "rthip_create: %s", hipGetErrorString(e));
     }
     const char *env = getenv("RTHIP_COUNTERS");
@@ -1732,6 +1732,12 @@ static int render_frame(rthip_ctx *c, const rthip_camera *cam, uint32_t n_frames
             hipError_t e2 = hipStreamEndCapture(c->stream, &graph);
             if (e2 != hipSuccess) e = e2;
         }
+        if (e == hipSuccess && erc == 0 && interrupted) {  // rthip_interrupt arrived while capturing: the graph is incomplete, never cache it
+            if (graph) (void)hipGraphDestroy(graph);
+            c->seen_key.clear();
+            c->last.pixels = 0;
+            return fail(RTHIP_E_INTERRUPTED, "rthip_render: interrupted");
+        }
         if (e == hipSuccess && erc == 0 && graph) e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
         if (graph) (void)hipGraphDestroy(graph);
         if (e == hipSuccess && erc == 0 && exec) {
@@ -1975,7 +1981,7 @@ int rthip_probe_cast(rthip_ctx *c, uint32_t n, const double *o, const double *d,
 int rthip_probe_noise(rthip_ctx *c, int32_t noise, uint32_t n, const double *p, double *out) {
     PROBE_PROLOGUE(true)
     if (!p || !out) return fail(RTHIP_E_INVALID, "rthip_probe_noise: null argument");
-    if (noise < 0) return fail(RTHIP_E_INVALID, "rthip_probe_noise: noise %d", noise);
+    if (noise < 0 || (uint32_t)noise >= c->uploaded.n_noises) return fail(RTHIP_E_INVALID, "rthip_probe_noise: noise %d not in [0,%u)", noise, c->uploaded.n_noises);
     void *pp, *po;
     if ((rc = probe_in(c, 0, p, sizeof(double) * 3 * n, &pp)) || (rc = probe_in(c, 1, nullptr, sizeof(double) * n, &po))) return rc;
     hipLaunchKernelGGL(k_probe_noise, dim3(grid), dim3(kBlock), 0, c->stream, c->sv, noise, n, (const double *)pp, (double *)po);
@@ -1986,7 +1992,8 @@ int rthip_probe_noise(rthip_ctx *c, int32_t noise, uint32_t n, const double *p, 
 }
 int rthip_probe_material(rthip_ctx *c, int32_t material, uint32_t n, const double *p, double *color, double *absorptance) {
     PROBE_PROLOGUE(true)
-    if (!p || !color || !absorptance || material < 0) return fail(RTHIP_E_INVALID, "rthip_probe_material: bad argument");
+    if (!p || !color || !absorptance) return fail(RTHIP_E_INVALID, "rthip_probe_material: null argument");
+    if (material < 0 || (uint32_t)material >= c->uploaded.n_materials) return fail(RTHIP_E_INVALID, "rthip_probe_material: material %d not in [0,%u)", material, c->uploaded.n_materials);
     void *pp, *pc, *pa;
     if ((rc = probe_in(c, 0, p, sizeof(double) * 3 * n, &pp)) || (rc = probe_in(c, 1, nullptr, sizeof(double) * 3 * n, &pc)) ||
         (rc = probe_in(c, 2, nullptr, sizeof(double) * n, &pa)))

@@ -181,11 +181,12 @@ void HipRaytracer::RenderThread(Scene *scene, std::promise<RenderStatus> p) {
     }
     m_Finished = true;  // Raytracer.cpp:76-77
     // release the renderer BEFORE publishing the result: the owner may destroy it as soon as the future is ready
+    // (notified under the lock: a destructor waiting in m_Idle cannot run before this thread is done with *this)
     {
         std::lock_guard<std::mutex> lock(m_Mutex);
         m_Busy = false;
+        m_Idle.notify_all();
     }
-    m_Idle.notify_all();
     if (rc)
         p.set_exception(std::make_exception_ptr(DeviceError(rc, err)));
     else

@@ -396,6 +396,18 @@ def test_update_scene_rejects_other_geometry(ctx):
     assert np.array_equal(a, ctx.render(big.camera(w, h), device.make_params(w, h, 2))["pixels"])
 
 
+def test_probes_reject_indices_outside_the_scene(ctx):
+    hs = host.HostScene(scenes.config(2)[0])
+    d = hs.flatten()
+    ctx.upload(d)
+    pts = np.zeros((4, 3))
+    for bad in (-1, 10 ** 6):
+        with pytest.raises(device.RthipError):
+            ctx.probe_noise(bad, pts)
+        with pytest.raises(device.RthipError):
+            ctx.probe_material(bad, pts)
+
+
 def test_render_contract_async_status_interrupt():
     """AbstractRaycaster::Render contract (Raytracer.cpp:34-99): returns at once, status pollable, promise
     satisfied exactly once with Finished = true — also after Interrupt()."""
