@@ -97,8 +97,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--inflight", type=int, default=0, help="frames in flight (one context + HIP stream each); 0 = 3 on one GPU, 4 on several "
-                    "(a rank's share of a frame is small: more of its latency-bound kernel chain has to overlap)")
+    ap.add_argument("--inflight", type=int, default=0, help="calls in flight (one context + HIP stream each); 0 = 3")
     ap.add_argument("--batch", type=int, default=0, help="frames traced per call (rthip_render_batch_device: one set of launches for "
                     "the rays of all of them); 0 = 8 on one GPU, 16 (the library's limit) on several")
     ap.add_argument("--latency", action="store_true", help="also measure the latency of ONE frame with nothing else in flight "
