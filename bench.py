@@ -106,6 +106,9 @@ def main():
     ap.add_argument("--collective", choices=["gather", "all_gather"], default="gather", help="framebuffer exchange: gather to rank 0 "
                     "(each peer sends its part once) or all-gather (every rank ends up with the frames)")
     ap.add_argument("--force-gather", action="store_true", help="run the RCCL gather + assemble path even with one rank")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true", help="torch.distributed.run with N ranks that all use GPU 0 and exchange "
+                    "over gloo (staged through host memory): walks the multi-rank control flow of this script on a one-GPU box; the "
+                    "number it prints is not a measurement")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -117,8 +120,13 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the Raycast path has no CPU fallback")
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if world > 1 and args.rehearse_on_one_gpu:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    elif world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     elif args.force_gather:  # rehearsal of the multi-GPU data path on one GPU
@@ -239,7 +247,7 @@ def main():
     st = pctx.stats()
     pctx.close()
     launch_ms = st.ms_trace / max(1, st.launches_trace)
-    total_rays = torch.tensor([float(my_rays), dt], dtype=torch.float64, device="cuda")
+    total_rays = torch.tensor([float(my_rays), dt], dtype=torch.float64, device="cpu" if args.rehearse_on_one_gpu else "cuda")
     if world > 1:
         rays_t = total_rays[:1].clone(); dist.all_reduce(rays_t, op=dist.ReduceOp.SUM)
         dt_t = total_rays[1:].clone(); dist.all_reduce(dt_t, op=dist.ReduceOp.MAX)
@@ -256,6 +264,7 @@ def main():
             "metric": "Mrays/sec (primary+bounce) 1080p OBJ KD-tree scene", "value": value, "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            **({"rehearsal": "all ranks on one GPU, gloo exchange through host memory: not a measurement"} if args.rehearse_on_one_gpu else {}),
             "config": {"workload": "BASELINE configs[2]: Demo 4 bunny.obj (4968 tris, kd-tree) + checker plane + SkyBox sun, "
                                    "1920x1080, MaxRecursion 3, camera (0,0,5)", "rays_per_frame": int(rays_frame),
                        "partition": f"interleaved 32x8 screen tiles over {world} GPU(s)" + (f", RCCL {args.collective} + device assemble" if gather else ""),

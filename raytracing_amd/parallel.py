@@ -61,6 +61,14 @@ def collect_parts(mine, gathered, how="gather", dst=0):
     import torch.distributed as dist
     world, rank = dist.get_world_size(), dist.get_rank()
     assert gathered.numel() == mine.numel() * world
+    if mine.is_cuda and dist.get_backend() == "gloo":
+        # rehearsal of the multi-rank control flow with every rank on ONE GPU (bench.py --rehearse-on-one-gpu; RCCL refuses
+        # two ranks on a device, gloo has no device gather): the exchange is staged through host memory
+        host_mine, host_all = mine.cpu(), gathered.cpu()
+        complete = collect_parts(host_mine, host_all, how, dst)
+        if complete:
+            gathered.copy_(host_all)
+        return complete
     if how == "all_gather":
         dist.all_gather_into_tensor(gathered, mine)
         return True

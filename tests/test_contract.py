@@ -52,3 +52,24 @@ def test_smoke_entry_point():
     r = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.smoke(); print('smoke ok')"], capture_output=True, text=True,
                        timeout=280, cwd=ROOT)
     assert r.returncode == 0 and "smoke ok" in r.stdout, (r.stdout + r.stderr)[-2000:]
+
+
+@pytest.mark.gpu
+def test_bench_multi_rank_control_flow_on_one_gpu():
+    """bench.py under torch.distributed.run with two ranks that share GPU 0 and exchange over gloo (RCCL refuses two ranks
+    on one device): the N > 1 branch of the script end to end — tile partition, per-rank ray counts summed, gather to
+    rank 0, device assemble.  The assembled frame is the single-GPU frame; the throughput it prints is not a measurement."""
+    one = _run_bench("--steps", "8", "--warmup", "8", "--no-cpu-baseline")
+    assert one.returncode == 0, one.stderr[-2000:]
+    ref = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][0])
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "32", "--warmup", "8",
+                        "--rehearse-on-one-gpu"], capture_output=True, text=True, timeout=280, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "rank 0 alone prints the line"
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 32 and "rehearsal" in d
+    assert d["config"]["rays_per_frame"] == ref["config"]["rays_per_frame"] == 4589295      # the two parts' rays add up
+    assert d["config"]["frame_checksum"] == ref["config"]["frame_checksum"]                # gathered + assembled = the 1-GPU frame
+    assert d["config"]["frames_per_call"] == 16 and "cpu_baseline" not in d
