@@ -1,4 +1,6 @@
 #!/usr/bin/env python3
+"""GPU box: config 4 (2 M triangles, 4K) rendered through both mesh paths - accel = 0, the 4-wide BVH, and accel = 1,
+the reference's kd-tree - and the two frames compared pixel by pixel and id by id (they must be identical)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
