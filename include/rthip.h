@@ -309,6 +309,17 @@ int rthip_render_device(rthip_ctx *ctx, const rthip_camera *cam, const rthip_par
  * path is known ahead; also what keeps a GPU busy when its share of a frame is small (part_count > 1). */
 int rthip_render_batch_device(rthip_ctx *ctx, const rthip_camera *cams, uint32_t n_frames, const rthip_params *params,
                               void *d_pixels, int sync);
+/* rthip_render_device for callers that CANNOT ALLOCATE device memory (code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc).  No counterpart in the reference.  Same frame, same kernels, bit-identical output; the
+ * per-frame workspace (ray queues, hit / colour records, list counters) lives in a file-scope `static __device__` array of
+ * RTHIP_NOALLOC_SCRATCH_BYTES (64 MiB) that every GPU the library runs on holds until the process ends, instead of in
+ * hipMalloc'ed buffers, and the call performs no hipMalloc / hipFree / graph instantiation / event creation.  Limits: one
+ * frame; the workspace, (36 * (max_recursion + 1) + 216) bytes per level-0 ray (x9 with SSAA) plus ~20 KB, must fit the
+ * array (e.g. 512x360 at MaxRecursion 3) - larger frames are rejected with RTHIP_E_UNSUPPORTED and a message that names the
+ * size; no id images, no statistics.  All contexts of one GPU share that GPU's array: calls that overlap on one GPU race
+ * (the array keeps the previous call's records; the counters that must start at zero are cleared by the call itself). */
+#define RTHIP_NOALLOC_SCRATCH_BYTES (64u << 20)
+int rthip_render_device_noalloc(rthip_ctx *ctx, const rthip_camera *cam, const rthip_params *params, void *d_pixels, int sync);
 /* number of uint32 entries of one part's tile-compact buffer (identical for every part_index:
  * ceil(n_tiles / part_count) * tile_w * tile_h), 0 on bad params */
 uint64_t rthip_part_pixels(const rthip_params *params);

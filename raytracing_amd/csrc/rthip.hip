@@ -26,6 +26,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -71,6 +72,16 @@ struct DevBuf {
 };
 
 static const uint32_t kBlock = 256;           // 4 waves per workgroup
+
+// Workspace of rthip_render_device_noalloc (include/rthip.h): the per-frame records that render_frame otherwise keeps in
+// hipMalloc'ed DevBufs, for callers that cannot allocate.  Every GPU the library runs on holds its own copy of this array
+// at its own address until the process ends.  In host code the NAME below is only a stand-in for the symbol: the device
+// address is taken once per device with hipGetSymbolAddress (rthip_create, that device current) and kept in
+// g_scratch_ptr[device]; host code only ever uses that pointer (kernel arguments included).
+static __device__ __align__(256) unsigned char scratch[RTHIP_NOALLOC_SCRATCH_BYTES];
+static const int kMaxDevices = 64;
+static void *g_scratch_ptr[kMaxDevices];   // device address of `scratch` on device d, nullptr until a context exists there
+static std::mutex g_scratch_mutex;
 // minimum waves per SIMD the register allocator must leave room for (the kernels are
 // bound by dependent fp64 chains, so resident waves matter more than a few spilled values)
 #ifndef RT_TRACE_OCC
@@ -1239,6 +1250,18 @@ int rthip_create(int device, rthip_ctx **out) {
     rthip_ctx *c = new rthip_ctx;
     c->device = device;
     if (set_device(c)) { delete c; return RTHIP_E_HIP; }
+    if (device < kMaxDevices) {  // once per device, with that device current: where this GPU's copy of `scratch` lives
+        std::lock_guard<std::mutex> lock(g_scratch_mutex);
+        if (!g_scratch_ptr[device]) {
+            void *sp = nullptr;
+            hipError_t se = hipGetSymbolAddress(&sp, HIP_SYMBOL(scratch));
+            if (se != hipSuccess || !sp) {
+                delete c;
+                return fail(RTHIP_E_HIP, "rthip_create: hipGetSymbolAddress(scratch) on device %d: %s", device, hipGetErrorString(se));
+            }
+            g_scratch_ptr[device] = sp;
+        }
+    }
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate(&c->ev0);
     if (e == hipSuccess) e = hipEventCreate(&c->ev1);
@@ -1518,8 +1541,10 @@ static int check_params(const rthip_camera *cam, const rthip_params *p) {
 
 // renders this context's part of n_frames frames (one camera each) into d_pixels (device; frame after frame, each
 // W*H or, tile-compact, rthip_part_pixels) and optionally device id images (single frames only)
+// noalloc: the workspace is carved out of this device's `scratch` array (g_scratch_ptr) instead of the context's DevBufs;
+// no HIP graph, no event pool, no chunking - nothing on that path allocates (rthip_render_device_noalloc).
 static int render_frame(rthip_ctx *c, const rthip_camera *cam, uint32_t n_frames, const rthip_params *p, uint32_t *d_pixels,
-                        int32_t *d_shape, int32_t *d_tri) {
+                        int32_t *d_shape, int32_t *d_tri, bool noalloc = false) {
     int rc = check_params(cam, p);
     if (rc) return rc;
     if (n_frames == 0 || n_frames > RTHIP_MAX_BATCH) return fail(RTHIP_E_INVALID, "rthip_render: %u frames per call, limit %d", n_frames, RTHIP_MAX_BATCH);
@@ -1559,32 +1584,62 @@ static int render_frame(rthip_ctx *c, const rthip_camera *cam, uint32_t n_frames
     if (tiles_per_chunk > my_tiles) tiles_per_chunk = my_tiles ? my_tiles : 1;
     const size_t N = (size_t)tiles_per_chunk * per_tile * spp;
 
-    if (c->rec.ensure(sizeof(ColRec) * N * levels)) return RTHIP_E_HIP;
-    if (c->child.ensure(sizeof(uint32_t) * N * levels)) return RTHIP_E_HIP;
-    if (c->rays.ensure(sizeof(RayRec) * 2 * N)) return RTHIP_E_HIP;
-    if (c->counts.ensure(sizeof(uint32_t) * kCounterSlots * kCounterStride)) return RTHIP_E_HIP;
-    if (c->stats.ensure(sizeof(unsigned long long) * ST_COUNT)) return RTHIP_E_HIP;
-    c->bs_stride = (uint32_t)((N + kBlock - 1) / kBlock);
-    c->bs_levels = levels;
-    if (c->block_stats.ensure(sizeof(uint2) * 2 * (size_t)c->bs_stride * levels)) return RTHIP_E_HIP;
-    if (c->ids.ensure(sizeof(int32_t) * 2 * (size_t)tiles_per_chunk * per_tile)) return RTHIP_E_HIP;
-    if (c->hits.ensure(sizeof(HitSlot) * N)) return RTHIP_E_HIP;
-    if (c->redo.ensure(sizeof(uint32_t) * 2 * N)) return RTHIP_E_HIP;
-    if (c->pend.ensure(sizeof(PendRec) * N)) return RTHIP_E_HIP;
     Work w;
-    w.rec = (ColRec *)c->rec.p;
-    w.child = (uint32_t *)c->child.p;
-    w.rays = (RayRec *)c->rays.p;
-    w.counts = (uint32_t *)c->counts.p;
-    w.stats = (unsigned long long *)c->stats.p;
-    w.id_shape = (d_shape || d_tri) ? (int32_t *)c->ids.p : nullptr;
-    w.id_tri = w.id_shape ? w.id_shape + (size_t)tiles_per_chunk * per_tile : nullptr;
-    w.hit = (HitSlot *)c->hits.p;
-    w.redo = (uint32_t *)c->redo.p;
+    uint32_t bs_stride = (uint32_t)((N + kBlock - 1) / kBlock);
+    if (!noalloc) {
+        if (c->rec.ensure(sizeof(ColRec) * N * levels)) return RTHIP_E_HIP;
+        if (c->child.ensure(sizeof(uint32_t) * N * levels)) return RTHIP_E_HIP;
+        if (c->rays.ensure(sizeof(RayRec) * 2 * N)) return RTHIP_E_HIP;
+        if (c->counts.ensure(sizeof(uint32_t) * kCounterSlots * kCounterStride)) return RTHIP_E_HIP;
+        if (c->stats.ensure(sizeof(unsigned long long) * ST_COUNT)) return RTHIP_E_HIP;
+        c->bs_stride = bs_stride;
+        c->bs_levels = levels;
+        if (c->block_stats.ensure(sizeof(uint2) * 2 * (size_t)c->bs_stride * levels)) return RTHIP_E_HIP;
+        if (c->ids.ensure(sizeof(int32_t) * 2 * (size_t)tiles_per_chunk * per_tile)) return RTHIP_E_HIP;
+        if (c->hits.ensure(sizeof(HitSlot) * N)) return RTHIP_E_HIP;
+        if (c->redo.ensure(sizeof(uint32_t) * 2 * N)) return RTHIP_E_HIP;
+        if (c->pend.ensure(sizeof(PendRec) * N)) return RTHIP_E_HIP;
+        w.rec = (ColRec *)c->rec.p;
+        w.child = (uint32_t *)c->child.p;
+        w.rays = (RayRec *)c->rays.p;
+        w.counts = (uint32_t *)c->counts.p;
+        w.stats = (unsigned long long *)c->stats.p;
+        w.id_shape = (d_shape || d_tri) ? (int32_t *)c->ids.p : nullptr;
+        w.id_tri = w.id_shape ? w.id_shape + (size_t)tiles_per_chunk * per_tile : nullptr;
+        w.hit = (HitSlot *)c->hits.p;
+        w.redo = (uint32_t *)c->redo.p;
+        w.pend = (PendRec *)c->pend.p;
+        w.block_stats = (uint2 *)c->block_stats.p;
+    } else {
+        // the same records, one after the other in this GPU's `scratch` array (256-byte aligned each)
+        if (tiles_per_chunk < my_tiles)
+            return fail(RTHIP_E_UNSUPPORTED, "rthip_render_device_noalloc: %ux%u (x%u frames%s) is %zu level-0 rays, more than one workspace chunk (%zu)",
+                        p->width, p->height, n_frames, fp.aa ? ", SSAA" : "", (size_t)my_tiles * per_tile * spp, c->chunk_rays);
+        unsigned char *base = c->device < kMaxDevices ? (unsigned char *)g_scratch_ptr[c->device] : nullptr;
+        if (!base) return fail(RTHIP_E_STATE, "rthip_render_device_noalloc: no scratch address for device %d", c->device);
+        size_t off = 0;
+        auto take = [&](size_t bytes) {
+            unsigned char *q = base + off;
+            off += (bytes + 255) & ~(size_t)255;
+            return q;
+        };
+        w.rec = (ColRec *)take(sizeof(ColRec) * N * levels);
+        w.child = (uint32_t *)take(sizeof(uint32_t) * N * levels);
+        w.rays = (RayRec *)take(sizeof(RayRec) * 2 * N);
+        w.counts = (uint32_t *)take(sizeof(uint32_t) * kCounterSlots * kCounterStride);
+        w.stats = (unsigned long long *)take(sizeof(unsigned long long) * 2 * ST_COUNT);
+        w.block_stats = (uint2 *)take(sizeof(uint2) * 2 * (size_t)bs_stride * levels);
+        w.hit = (HitSlot *)take(sizeof(HitSlot) * N);
+        w.redo = (uint32_t *)take(sizeof(uint32_t) * 2 * N);
+        w.pend = (PendRec *)take(sizeof(PendRec) * N);
+        w.id_shape = w.id_tri = nullptr;
+        if (off > RTHIP_NOALLOC_SCRATCH_BYTES)
+            return fail(RTHIP_E_UNSUPPORTED, "rthip_render_device_noalloc: %ux%u, max_recursion %u%s needs a %zu-byte workspace, the static scratch "
+                        "holds %u (about %zu level-0 rays at this recursion depth)", p->width, p->height, p->max_recursion, fp.aa ? ", SSAA" : "",
+                        off, RTHIP_NOALLOC_SCRATCH_BYTES, (size_t)RTHIP_NOALLOC_SCRATCH_BYTES / (36 * (size_t)levels + 216));
+    }
     w.hard = w.redo + N;
-    w.pend = (PendRec *)c->pend.p;
-    w.block_stats = (uint2 *)c->block_stats.p;
-    w.bs_stride = c->bs_stride;
+    w.bs_stride = bs_stride;
     w.N = (uint32_t)N;
 
     c->sv.accel = p->accel;
@@ -1608,7 +1663,8 @@ static int render_frame(rthip_ctx *c, const rthip_camera *cam, uint32_t n_frames
 
     // ---- what a cached graph depends on
     const bool single_chunk = tiles_per_chunk >= my_tiles;
-    const bool use_graph = c->graphs_enabled && single_chunk && !c->profile_launches;
+    const bool profile = c->profile_launches && !noalloc;
+    const bool use_graph = c->graphs_enabled && single_chunk && !profile && !noalloc;
     std::vector<unsigned char> key;
     if (use_graph) {
         auto put = [&](const void *ptr, size_t n) { key.insert(key.end(), (const unsigned char *)ptr, (const unsigned char *)ptr + n); };
@@ -1636,7 +1692,7 @@ static int render_frame(rthip_ctx *c, const rthip_camera *cam, uint32_t n_frames
     bool interrupted = false;
     auto enqueue = [&]() -> int {
     {
-        const uint32_t na = 2 * ST_COUNT, nb = (uint32_t)(2 * 2 * (size_t)c->bs_stride * levels);
+        const uint32_t na = 2 * ST_COUNT, nb = (uint32_t)(2 * 2 * (size_t)bs_stride * levels);
         const uint32_t most = na > nb ? na : nb;
         hipLaunchKernelGGL(k_clear, dim3((most + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, (uint32_t *)w.stats, na,
                            (uint32_t *)w.block_stats, nb, (uint32_t *)nullptr, 0u);
@@ -1662,7 +1718,7 @@ static int render_frame(rthip_ctx *c, const rthip_camera *cam, uint32_t n_frames
             uint32_t grid = (fp.N0 + kBlock - 1) / kBlock;
             if (grid > kMaxGridLevel) grid = kMaxGridLevel;  // every level: the kernels stride over their rays (see kMaxGridLevel)
             hipEvent_t ea = nullptr, eq = nullptr, eb = nullptr, ec = nullptr;
-            if (c->profile_launches) {
+            if (profile) {
                 if (get_event(&ea) || get_event(&eq) || get_event(&eb) || get_event(&ec)) return RTHIP_E_HIP;
                 HIP_TRY(hipEventRecord(ea, c->stream));
             }
@@ -1673,7 +1729,7 @@ static int render_frame(rthip_ctx *c, const rthip_camera *cam, uint32_t n_frames
                     hipLaunchKernelGGL((k_trace_easy<true>), dim3(grid), dim3(kBlock), lds_tables, c->stream, c->sv, fp, w, level, c->n_tables, levels);
                 else
                     hipLaunchKernelGGL((k_trace_easy<false>), dim3(grid), dim3(kBlock), lds_tables, c->stream, c->sv, fp, w, level, c->n_tables, levels);
-                if (c->profile_launches) HIP_TRY(hipEventRecord(eq, c->stream));
+                if (profile) HIP_TRY(hipEventRecord(eq, c->stream));
                 if (c->has_meshes) {  // the rays that need a mesh walk (count on the device: the grid is an upper bound, strided)
                     uint32_t qgrid = (fp.N0 + quad::kRaysPerBlock - 1) / quad::kRaysPerBlock;
                     if (qgrid > kMaxGridQuad) qgrid = kMaxGridQuad;
@@ -1682,7 +1738,7 @@ static int render_frame(rthip_ctx *c, const rthip_camera *cam, uint32_t n_frames
                     else
                         hipLaunchKernelGGL((k_trace_quad<false>), dim3(qgrid), dim3(kBlock), lds_quad, c->stream, c->sv, fp, w, level, quad_cap);
                 }
-                if (c->profile_launches) HIP_TRY(hipEventRecord(eb, c->stream));
+                if (profile) HIP_TRY(hipEventRecord(eb, c->stream));
                 if (c->has_meshes) {  // re-trace of the (rare) rays lying exactly in a kd split plane or overflowing the short stack
                     if (c->count_kd)
                         hipLaunchKernelGGL((k_trace<true, true>), dim3(64), dim3(kBlock), lds_bytes, c->stream, c->sv, fp, w, level, c->stack_cap);
@@ -1690,12 +1746,12 @@ static int render_frame(rthip_ctx *c, const rthip_camera *cam, uint32_t n_frames
                         hipLaunchKernelGGL((k_trace<true, false>), dim3(64), dim3(kBlock), lds_bytes, c->stream, c->sv, fp, w, level, c->stack_cap);
                 }
             } else {
-                if (c->profile_launches) HIP_TRY(hipEventRecord(eq, c->stream));
+                if (profile) HIP_TRY(hipEventRecord(eq, c->stream));
                 if (c->count_kd)
                     hipLaunchKernelGGL((k_trace<false, true>), dim3(grid), dim3(kBlock), lds_bytes, c->stream, c->sv, fp, w, level, c->stack_cap);
                 else
                     hipLaunchKernelGGL((k_trace<false, false>), dim3(grid), dim3(kBlock), lds_bytes, c->stream, c->sv, fp, w, level, c->stack_cap);
-                if (c->profile_launches) HIP_TRY(hipEventRecord(eb, c->stream));
+                if (profile) HIP_TRY(hipEventRecord(eb, c->stream));
             }
             if (p->accel == 0) {
                 if (c->has_meshes)
@@ -1703,7 +1759,7 @@ static int render_frame(rthip_ctx *c, const rthip_camera *cam, uint32_t n_frames
             } else {
                 hipLaunchKernelGGL((k_shade<false>), dim3(grid), dim3(kBlock), lds_tables, c->stream, c->sv, fp, w, level, c->n_tables, levels);
             }
-            if (c->profile_launches) HIP_TRY(hipEventRecord(ec, c->stream));
+            if (profile) HIP_TRY(hipEventRecord(ec, c->stream));
         }
         hipLaunchKernelGGL(k_resolve, dim3((fp.n_pix_slots + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, fp, w,
                            d_pixels, d_shape, d_tri);
@@ -1852,6 +1908,14 @@ int rthip_render_batch_device(rthip_ctx *c, const rthip_camera *cams, uint32_t n
     int rc = render_frame(c, cams, n_frames, p, (uint32_t *)d_pixels, nullptr, nullptr);
     if (rc) return rc;
     if (sync) return finish_stats(c, p);
+    return 0;
+}
+
+int rthip_render_device_noalloc(rthip_ctx *c, const rthip_camera *cam, const rthip_params *p, void *d_pixels, int sync) {
+    if (!c || !d_pixels) return fail(RTHIP_E_INVALID, "rthip_render_device_noalloc: null argument");
+    int rc = render_frame(c, cam, 1, p, (uint32_t *)d_pixels, nullptr, nullptr, true);
+    if (rc) return rc;
+    if (sync) HIP_TRY(hipStreamSynchronize(c->stream));  // (no statistics: reading them back would stage through the runtime)
     return 0;
 }
 

@@ -19,7 +19,7 @@ SYMBOLS = ["rthip_create", "rthip_destroy", "rthip_last_error", "rthip_upload_sc
            "rthip_get_stats", "rthip_probe_cast", "rthip_probe_noise", "rthip_probe_material",
            "rthip_probe_background", "rthip_probe_raycast", "rthip_probe_arith", "rthip_version",
            "rthip_part_pixels", "rthip_assemble", "rthip_render_batch_device", "rthip_assemble_batch", "rthip_host_alloc",
-           "rthip_host_free", "rthip_update_scene"]
+           "rthip_host_free", "rthip_update_scene", "rthip_render_device_noalloc"]
 MAX_BATCH = 16  # RTHIP_MAX_BATCH
 
 
@@ -80,6 +80,7 @@ def lib():
     L.rthip_update_scene.argtypes = [vp, vp]
     L.rthip_render.argtypes = [vp, C.POINTER(Camera), C.POINTER(Params), c_u32p, c_i32p, c_i32p]
     L.rthip_render_device.argtypes = [vp, C.POINTER(Camera), C.POINTER(Params), vp, C.c_int]
+    L.rthip_render_device_noalloc.argtypes = [vp, C.POINTER(Camera), C.POINTER(Params), vp, C.c_int]
     L.rthip_part_pixels.argtypes = [C.POINTER(Params)]
     L.rthip_part_pixels.restype = C.c_uint64
     L.rthip_assemble.argtypes = [vp, C.POINTER(Params), vp, vp, C.c_int]
@@ -161,6 +162,10 @@ class Context:
 
     def render_device(self, cam, params, d_pixels_ptr, sync=False):
         self._check(self.L.rthip_render_device(self.h, C.byref(cam), C.byref(params), C.c_void_p(d_pixels_ptr), int(sync)))
+
+    def render_device_noalloc(self, cam, params, d_pixels_ptr, sync=False):
+        """rthip_render_device with the workspace in the library's static device array: no device allocation in the call"""
+        self._check(self.L.rthip_render_device_noalloc(self.h, C.byref(cam), C.byref(params), C.c_void_p(d_pixels_ptr), int(sync)))
 
     def assemble(self, params, d_gathered_ptr, d_frame_ptr, sync=False):
         self._check(self.L.rthip_assemble(self.h, C.byref(params), C.c_void_p(d_gathered_ptr), C.c_void_p(d_frame_ptr), int(sync)))

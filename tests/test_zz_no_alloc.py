@@ -1,0 +1,59 @@
+"""rthip_render_device_noalloc (include/rthip.h): the entry point that allocates nothing.  Its workspace is the library's
+static device array instead of hipMalloc'ed buffers; everything else (kernels, launch order) is rthip_render_device's, so
+the output must be bit-identical.  Two calls in a row on one context, the second with a smaller frame (the array keeps the
+first call's records), each compared with rthip_render_device through the C-ABI; plus the size limit's error."""
+import numpy as np
+import pytest
+import torch
+
+from raytracing_amd import device, host, scenes
+
+pytestmark = pytest.mark.gpu
+
+
+def _frames(ctx, hs, w, h, max_rec, aa=0):
+    cam = hs.camera(w, h)
+    prm = device.make_params(w, h, max_rec, aa=aa)
+    want = torch.zeros(w * h, dtype=torch.int32, device="cuda")
+    got = torch.full((w * h,), 0x5a5a5a5a, dtype=torch.int32, device="cuda")
+    ctx.render_device(cam, prm, want.data_ptr(), sync=True)
+    ctx.render_device_noalloc(cam, prm, got.data_ptr(), sync=True)
+    return got.cpu().numpy(), want.cpu().numpy()
+
+
+def test_noalloc_entry_point_matches_render_device_twice_in_a_row_second_smaller():
+    sd, _ = scenes.config(3, cam_z=2.5)   # bunny (BVH walk, hard list, redo list) + checker plane + SkyBox: every kernel runs
+    hs = host.HostScene(sd)
+    ctx = device.Context(0)
+    try:
+        ctx.upload(hs.flatten())
+        for (w, h, rec, aa) in [(320, 200, 3, 0), (136, 72, 2, 0), (96, 40, 1, 1)]:   # second smaller, third SSAA + smaller still
+            got, want = _frames(ctx, hs, w, h, rec, aa)
+            assert len(np.unique(want)) > 50, "the comparison frame is not a rendering"
+            assert np.array_equal(got, want), f"{w}x{h}: {(got != want).sum()} pixels differ from rthip_render_device"
+        # beyond the static array: a clear error, nothing rendered, the context stays usable
+        cam = hs.camera(1920, 1080)
+        big = torch.zeros(1920 * 1080, dtype=torch.int32, device="cuda")
+        with pytest.raises(device.RthipError) as e:
+            ctx.render_device_noalloc(cam, device.make_params(1920, 1080, 3), big.data_ptr(), sync=True)
+        assert e.value.code == -3 and "workspace" in str(e.value) and "scratch" in str(e.value)
+        assert int(big.abs().sum().item()) == 0
+        got, want = _frames(ctx, hs, 64, 64, 3)
+        assert np.array_equal(got, want)
+    finally:
+        ctx.close()
+
+
+def test_noalloc_on_a_second_context_of_the_same_gpu_shares_the_array():
+    """every context of a GPU uses that GPU's one array (calls must not overlap): back-to-back calls on two contexts"""
+    hs = host.HostScene(scenes.config(2)[0])
+    a, b = device.Context(0), device.Context(0)
+    try:
+        a.upload(hs.flatten())
+        b.upload(hs.flatten())
+        ga, wa = _frames(a, hs, 160, 90, 3)
+        gb, wb = _frames(b, hs, 120, 64, 3)
+        assert np.array_equal(ga, wa) and np.array_equal(gb, wb)
+    finally:
+        a.close()
+        b.close()
