@@ -17,9 +17,14 @@ path rendered ahead of time looks like; it is also what keeps a GPU busy when it
 eighth of it (a frame is ~20 dependent launches, each of them latency-bound on so few rays).  --steps K times exactly
 K frames: K // batch full calls and one shorter call.  --latency also reports the latency of a single frame.
 
-Prints ONE JSON line (rank 0).  Extra objects: "roofline" (dominant kernel k_trace_quad, algorithmic
-bytes from SURVEY.md §8d's per-ray formula with counts measured on this frame) and "cpu_baseline"
-(the genuine reference compiled in oracle/_ref — or the C oracle port — timed on the host cores).
+Prints ONE JSON line (rank 0).  Extra objects: "roofline" (dominant kernel k_trace_quad: algorithmic VALU flops from
+SURVEY.md §8d's per-unit weights x counts measured on this call, against the fp64 vector peak; the HBM fraction next to it
+from the PMC-measured traffic), "config4" (BASELINE configs[3], the 2 M-triangle 4K frame: the config whose roof IS HBM),
+"single_frame_latency_ms" / "ms_per_frame_with_d2h" in "config", and "cpu_baseline" (the genuine reference compiled in
+oracle/_ref - or the C oracle port - timed on the host cores, NumThreads 16 and 8, medians of 3 frames).
+
+`python bench.py --gpus N` with N > 1 and no launcher around it starts its own N ranks (torch.distributed.run as a child
+process) and relays rank 0's line and the exit code.
 """
 import argparse
 import ctypes as C
@@ -33,41 +38,64 @@ sys.path.insert(0, ROOT)
 
 W, H, MAX_REC = 1920, 1080, 3
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s peak (spec)
+# fp64 vector peak: 256 CUs x 4 SIMDs x 16 lanes x 2 flops (FMA) x 2.4 GHz = 78.6 TFLOP/s (the guide's 157.3 TFLOP/s
+# fp32 vector figure is twice that through packed fp32).  The kernels are built with -ffp-contract=off (bit parity with the
+# non-fused x86-64 reference), so every fp64 instruction is ONE flop: the usable peak of this code is half, 39.3 TFLOP/s.
+FP64_VALU_PEAK_TFLOPS = 78.6
+FP64_VALU_PEAK_UNFUSED_TFLOPS = 39.3
+PMC_CFG3 = os.path.join("profiles", "r02_pmc_summary_config3_batch8.json")
+PMC_CFG4 = os.path.join("profiles", "r02_pmc_summary_config4.json")
+PMC_TRAFFIC = os.path.join("profiles", "r02_pmc_traffic.json")
 
 
-def algorithmic_bytes(st):
-    """Algorithmic bytes of the DOMINANT kernel (k_trace_quad: the mesh walk of the rays that need one), SURVEY.md
-    §8(d) restated for this implementation's records: 128 B per BVH node step (one line per ray and step), 128 + 4 B
-    per triangle tested (record + index), 72 B of vertex normals per mesh hit, 2 x 96 B of matrices per shape-table
-    entry tested, 64 B ray record in + 64 B hit record out per ray it traces."""
-    return (128 * st.kd_nodes_visited + 132 * st.kd_tris_tested + 72 * st.mesh_hits + 192 * st.shape_tests + 128 * st.rays_hard)
+# ALGORITHMIC flops of the dominant kernel (SURVEY.md §8d "ALGORITHMIC flops per ray": fixed weights x measured counts), for
+# k_trace_quad's units of work:
+#   72 per BVH step  : 4 child boxes x (6 fma = 12 flops + 6 min/max) - fp32 VALU, counted as issued (unpacked fp32 and fp64
+#                      instructions take the same issue slot on CDNA4)
+#   54 per triangle  : Mesh::IntersectTriangle + Baricentric in fp64 (Scene.cpp:421-467, 495-507): two 3-dots for the plane
+#                      (10 + 3 sub), the hit point (1 div + 6), v2 (3), two more dots (10), v / w / u (10), |O-P|^2 (8), compares
+#   180 per shape-table entry tested: SURVEY's weight (two 4x4 mat-vec, normalise, intersect, world point, d^2)
+#   140 per ray      : hit record of the winner (hit_details: transforms, barycentric normal blend, two normalisations)
+FLOPS_NODE, FLOPS_TRI, FLOPS_SHAPE, FLOPS_RAY = 72, 54, 180, 140
 
 
-def measured_traffic(launches):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/r01_pmc_traffic.json,
-    produced by tools/prof_traffic.sh: separate rocprofv3 --pmc runs of FETCH_SIZE and WRITE_SIZE over this very
-    workload, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950)."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if not os.path.exists(path):
+def algorithmic_flops(st):
+    return FLOPS_NODE * st.kd_nodes_visited + FLOPS_TRI * st.kd_tris_tested + FLOPS_SHAPE * st.shape_tests + FLOPS_RAY * st.rays_hard
+
+
+def _load(rel):
+    path = os.path.join(ROOT, rel)
+    return json.load(open(path)) if os.path.exists(path) else None
+
+
+def measured_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (tools/prof_traffic.sh: separate rocprofv3
+    --pmc runs of FETCH_SIZE and WRITE_SIZE over this very workload, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes
+    for gfx950)."""
+    t = _load(PMC_TRAFFIC) or _load(os.path.join("profiles", "r01_pmc_traffic.json"))
+    return None if t is None else t.get("k_trace_quad_bytes_per_launch")
+
+
+def measured_valu(rel=PMC_CFG3, fallback=os.path.join("profiles", "r01_pmc_summary_config3_batch8.json")):
+    """VALU issue utilisation / active lanes / waiting fraction of the dominant kernel from the committed PMC passes over the
+    bench's own shape of work (`tools/prof_passes.sh <tag> 3 4 8` + prof_summary.py): the measured side of the VALU roof."""
+    src = rel if _load(rel) else fallback
+    j = _load(src)
+    if j is None:
         return None
-    t = json.load(open(path))
-    return t.get("k_trace_quad_bytes_per_launch")
-
-
-def measured_valu():
-    """VALU issue utilisation / waiting fraction of the dominant kernel from the committed PMC passes over the
-    bench's own shape of work, 8-frame calls of config 3 (profiles/r01_pmc_summary_config3_batch8.json,
-    `tools/prof_passes.sh <tag> 3 4 8` + prof_summary.py): what actually bounds it."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_summary_config3_batch8.json")
-    if not os.path.exists(path):
+    k = j["kernels"].get("k_trace_quad<false>")
+    if k is None:
         return None
-    k = json.load(open(path))["kernels"].get("k_trace_quad<false>")
-    return None if k is None else {"valu_issue_util": k["valu_issue_util"], "wave_time_waiting": k["wave_time_waiting"], "l2_hit_rate": k["l2_hit_rate"],
-                                   "source": "profiles/r01_pmc_summary_config3_batch8.json"}
+    out = {key: k[key] for key in ("valu_issue_util", "wave_time_waiting", "l2_hit_rate", "active_lanes_per_valu_inst") if key in k}
+    if "valu_issue_util" in out and "active_lanes_per_valu_inst" in out:
+        out["valu_lane_cycle_util"] = out["valu_issue_util"] * out["active_lanes_per_valu_inst"] / 64.0
+    out["source"] = src
+    return out
 
 
-def cpu_baseline(sd, max_seconds=25.0):
-    """Times the CPU renderer on the host cores on a bounded sample of the same workload."""
+def cpu_baseline(sd, frames=3):
+    """Times the CPU renderer on the host cores on a bounded sample of the same workload: `frames` whole 1080p frames at
+    NumThreads = min(16, host cores) and at NumThreads = 8 (the Sandbox's setting, Sandbox/Sandbox.cpp:139), medians."""
     import oracle
     cores = min(16, os.cpu_count() or 1)
     if oracle.have_ref():
@@ -75,20 +103,96 @@ def cpu_baseline(sd, max_seconds=25.0):
     else:
         lib, kind = oracle.load_oracle(), "port"
     scene = sd.build(lib)
-    # sample: full-width frames of reduced height are NOT used: the reference schedules columns, so the
-    # sample is a whole 1080p frame when it fits the time box, else a centred 960x540 frame.
-    w, h = W, H
-    t0 = time.time()
-    r = scene.render(w // 4, h // 4, max_recursion=MAX_REC, threads=cores)  # also compiles the scene (kd build)
-    probe = time.time() - t0
-    if probe * 16 > max_seconds:
-        w, h = W // 2, H // 2
-    t0 = time.time()
-    r = scene.render(w, h, max_recursion=MAX_REC, threads=cores)
-    dt = time.time() - t0
-    return {"value": r["rays"] / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": kind,
-            "sample": f"1 frame {w}x{h} of the same scene (MaxRecursion {MAX_REC}), {r['rays']} rays in {dt:.2f} s, NumThreads={cores}",
-            "ms_per_frame_sample": dt * 1e3}
+    scene.render(W // 8, H // 8, max_recursion=MAX_REC, threads=cores)  # compiles the scene (kd build) outside the timed frames
+
+    def median_frame(threads):
+        ts, rays = [], 0
+        for _ in range(frames):
+            t0 = time.time()
+            r = scene.render(W, H, max_recursion=MAX_REC, threads=threads)
+            ts.append(time.time() - t0)
+            rays = r["rays"]
+        ts.sort()
+        return ts[len(ts) // 2], rays, ts
+
+    dt, rays, all_t = median_frame(cores)
+    out = {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": kind,
+           "sample": f"median of {frames} whole frames {W}x{H} of the same scene (MaxRecursion {MAX_REC}, {rays} rays each), NumThreads={cores}: "
+                     + ", ".join(f"{t:.2f}" for t in all_t) + " s",
+           "ms_per_frame_sample": dt * 1e3}
+    if cores != 8:
+        dt8, rays8, all8 = median_frame(8)
+        out["threads8"] = {"value": rays8 / dt8 / 1e6, "unit": "Mrays/s", "cores": 8, "ms_per_frame_sample": dt8 * 1e3,
+                           "sample": f"median of {frames} frames, NumThreads=8 (Sandbox/Sandbox.cpp:139): " + ", ".join(f"{t:.2f}" for t in all8) + " s"}
+    return out
+
+
+def config4_line(local_rank, frames=5):
+    """BASELINE configs[3] on ONE GPU, lone frames left in HBM: the 2 097 152-triangle height field + 16 reflective spheres,
+    3840x2160, MaxRecursion 4 - the workload whose BVH + triangles (0.6 GB) do not fit L2, i.e. where HBM is the roof."""
+    import torch
+    from raytracing_amd import device, host, scenes
+    t0 = time.perf_counter()
+    sd, kw = scenes.config(4)
+    hs = host.HostScene(sd, device_index=local_rank)
+    desc = hs.flatten()
+    t1 = time.perf_counter()
+    w, h, mr = kw["width"], kw["height"], kw["max_recursion"]
+    ctx = device.Context(local_rank)
+    ctx.upload(desc)
+    ctx.synchronize()
+    t2 = time.perf_counter()
+    cam, prm = hs.camera(w, h), device.make_params(w, h, mr)
+    fb = torch.zeros(w * h, dtype=torch.int32, device="cuda")
+    for _ in range(3):
+        ctx.render_device(cam, prm, fb.data_ptr(), sync=True)
+    st = ctx.stats()
+    rays = st.rays_primary + st.rays_shadow + st.rays_reflect
+    ts = []
+    for _ in range(frames):
+        t = time.perf_counter()
+        ctx.render_device(cam, prm, fb.data_ptr(), sync=True)
+        ts.append((time.perf_counter() - t) * 1e3)
+    ts.sort()
+    ms = ts[len(ts) // 2]
+    checksum = int(fb.to(torch.int64).sum().item())
+    ctx.close()
+    out = {"workload": "BASELINE configs[3]: 2 097 152-triangle height field + 16 reflective spheres + SkyBox, 3840x2160, MaxRecursion 4, lone frames",
+           "rays_per_frame": int(rays), "ms_per_frame": ms, "value": rays / ms / 1e3, "unit": "Mrays/s", "frames": frames,
+           "frame_checksum": checksum, "scene_build_s": t1 - t0, "scene_upload_s": t2 - t1}
+    pmc = _load(PMC_CFG4) or _load(os.path.join("profiles", "r01_pmc_summary_config4.json"))
+    k = pmc and pmc["kernels"].get("k_trace_quad<false>")
+    if k and k.get("hbm_bytes_per_frame"):
+        # HBM roof of the dominant kernel on THIS config: PMC bytes per frame (FETCH_SIZE x 2 + WRITE_SIZE, separate passes)
+        # over the kernel's own time in the same passes
+        gbs = k["hbm_bytes_per_frame"] / (k["gpu_ms_per_frame_serialised"] * 1e-3) / 1e9
+        out["roofline"] = {"bound": "hbm", "kernel": "k_trace_quad", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                           "traffic": k["hbm_bytes_per_frame"], "kernel_ms_per_frame": k["gpu_ms_per_frame_serialised"],
+                           "valu_issue_util": k.get("valu_issue_util"), "l2_hit_rate": k.get("l2_hit_rate"), "source": pmc.get("source_file")}
+    return out
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with no launcher around it: start the N ranks as a CHILD process (torch.distributed.run; never an
+    exec), relay rank 0's JSON line and the exit code.  Runs before torch is imported or HIP is touched in this process."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    sys.stdout.write(r.stdout)
+    sys.stdout.flush()
+    if r.returncode != 0:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: the {args.gpus}-rank run failed (exit code {r.returncode}); no result")
+    if len(lines) != 1:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: expected one JSON line from rank 0, got {len(lines)}")
+    raise SystemExit(0)
 
 
 def main():
@@ -100,9 +204,12 @@ def main():
     ap.add_argument("--inflight", type=int, default=0, help="calls in flight (one context + HIP stream each); 0 = 3")
     ap.add_argument("--batch", type=int, default=0, help="frames traced per call (rthip_render_batch_device: one set of launches for "
                     "the rays of all of them); 0 = 8 on one GPU, 16 (the library's limit) on several")
-    ap.add_argument("--latency", action="store_true", help="also measure the latency of ONE frame with nothing else in flight "
-                    "(off by default so that every k_trace_quad launch of a default run has the same size: the rocprofv3 --stats "
-                    "average of the same command is then comparable with roofline.avg_launch_ms)")
+    ap.add_argument("--latency", action="store_true", help="(kept for old command lines: lone-frame latency is measured by default now)")
+    ap.add_argument("--no-extras", action="store_true", help="skip what runs AFTER the timed region besides the roofline launches: the lone-frame "
+                    "latency, the D2H-inclusive frames and the config-4 frames.  For `rocprofv3 --kernel-trace --stats -- python3 bench.py "
+                    "--no-extras`: every k_trace_quad launch of the process then has the timed region's size, so the profiler's average "
+                    "duration of that kernel is comparable with roofline.avg_launch_ms")
+    ap.add_argument("--no-config4", action="store_true", help="skip the config-4 object (2 M-triangle scene: ~3 s of host build + 0.6 GB upload)")
     ap.add_argument("--collective", choices=["gather", "all_gather"], default="gather", help="framebuffer exchange: gather to rank 0 "
                     "(each peer sends its part once) or all-gather (every rank ends up with the frames)")
     ap.add_argument("--force-gather", action="store_true", help="run the RCCL gather + assemble path even with one rank")
@@ -110,18 +217,25 @@ def main():
                     "over gloo (staged through host memory): walks the multi-rank control flow of this script on a one-GPU box; the "
                     "number it prints is not a measurement")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)  # does not return
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: a run on fewer ranks than asked for is not reported as {args.gpus} GPUs")
     import torch
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the Raycast path has no CPU fallback")
     if args.rehearse_on_one_gpu:
         local_rank = 0
+    elif torch.cuda.device_count() < world:
+        raise SystemExit(f"--gpus {world} but only {torch.cuda.device_count()} GPU(s) visible: refusing to share devices (use --rehearse-on-one-gpu "
+                         "to walk the multi-rank control flow on one GPU)")
     torch.cuda.set_device(local_rank)
     if world > 1 and args.rehearse_on_one_gpu:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -157,7 +271,7 @@ def main():
     scratch = torch.zeros(B * (part_px if gather else W * H), dtype=torch.int32, device="cuda")
     cctx.render_batch_device(cam_runs[B], prm, scratch.data_ptr(), sync=True)
     cst = cctx.stats()
-    abytes = algorithmic_bytes(cst)  # per call
+    aflops = algorithmic_flops(cst)  # per call
     my_rays = (cst.rays_primary + cst.rays_shadow + cst.rays_reflect) // B  # per frame
     cctx.close()
     del scratch
@@ -227,26 +341,68 @@ def main():
     sync_all()
     dt = time.perf_counter() - t0
 
-    # latency of ONE frame (nothing else in flight), and the per-launch duration of the dominant kernel
-    # (HIP events on the context's own stream) on a profiling context
-    lat = []
-    for _ in range(10 if args.latency else 0):
-        t1 = time.perf_counter()
-        call(0, 1)
-        sync_all()
-        lat.append((time.perf_counter() - t1) * 1e3)
-    lat.sort()
+    # ---- after the timed region -------------------------------------------------------------------------------------
+    # (1) per-launch duration of the dominant kernel (HIP events on the contexts' own streams, plain launches instead of the
+    #     replayed graph): of a launch that has the GPU to itself, and of launches in the timed region's regime (F calls in
+    #     flight, one host thread per context so that F sets of launches overlap) - the figure `rocprofv3 --kernel-trace
+    #     --stats -- python3 bench.py --no-extras` reports as the kernel's average duration.
+    import threading
+    for c in ctxs:
+        c.synchronize()
+    os.environ["RTHIP_PROFILE_LAUNCHES"] = "1"
+    pctxs = [device.Context(local_rank) for _ in range(F)]
+    os.environ["RTHIP_PROFILE_LAUNCHES"] = "0"
+    for c in pctxs:
+        c.upload(desc)
+    for _ in range(3):
+        pctxs[0].render_batch_device(cam_runs[B], prm, mines[0].data_ptr(), sync=True)
+    st = pctxs[0].stats()
+    launch_ms = st.ms_trace / max(1, st.launches_trace)
+    over = []
+
+    def overlapped(j):
+        for _ in range(4):
+            pctxs[j].render_batch_device(cam_runs[B], prm, mines[j].data_ptr(), sync=True)
+            s2 = pctxs[j].stats()
+            over.append((s2.ms_trace, s2.launches_trace))
+    ths = [threading.Thread(target=overlapped, args=(j,)) for j in range(F)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    launch_ms_overlapped = sum(m for m, _ in over) / max(1, sum(n for _, n in over))
+    for c in pctxs:
+        c.close()
+
+    # (2) what the reference's own contract costs: ONE frame with nothing else in flight (latency), and the same frame
+    #     through rthip_render into page-locked host memory (RenderSync hands back host pixels: D2H-inclusive)
+    lat, d2h = [], []
+    cfg4 = None
+    if not args.no_extras:
+        for _ in range(3):
+            call(0, 1)
+            sync_all()
+        for _ in range(10):
+            t1 = time.perf_counter()
+            call(0, 1)
+            sync_all()
+            lat.append((time.perf_counter() - t1) * 1e3)
+        lat.sort()
+        if world == 1:
+            full = device.make_params(W, H, MAX_REC)
+            pinned = ctxs[0].host_pixels(W, H)
+            for _ in range(3):
+                ctxs[0].render(cam, full, out=pinned)
+            for _ in range(10):
+                t1 = time.perf_counter()
+                ctxs[0].render(cam, full, out=pinned)
+                d2h.append((time.perf_counter() - t1) * 1e3)
+            d2h.sort()
+            ctxs[0].host_free(pinned)
     for c in ctxs[1:]:
         c.close()
-    os.environ["RTHIP_PROFILE_LAUNCHES"] = "1"
-    pctx = device.Context(local_rank)
-    os.environ["RTHIP_PROFILE_LAUNCHES"] = "0"
-    pctx.upload(desc)
-    for _ in range(3):
-        pctx.render_batch_device(cam_runs[B], prm, mines[0].data_ptr(), sync=True)
-    st = pctx.stats()
-    pctx.close()
-    launch_ms = st.ms_trace / max(1, st.launches_trace)
+    if world == 1 and rank == 0 and not args.no_extras and not args.no_config4:
+        cfg4 = config4_line(local_rank)
     total_rays = torch.tensor([float(my_rays), dt], dtype=torch.float64, device="cpu" if args.rehearse_on_one_gpu else "cuda")
     if world > 1:
         rays_t = total_rays[:1].clone(); dist.all_reduce(rays_t, op=dist.ReduceOp.SUM)
@@ -259,7 +415,11 @@ def main():
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         value = rays_frame * args.steps / dt / 1e6
-        achieved = (abytes / max(1, st.launches_trace)) / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
+        n_launch = max(1, st.launches_trace)
+        tflops = (aflops / n_launch) / (launch_ms * 1e-3) / 1e12 if launch_ms > 0 else 0.0
+        traffic = measured_traffic()
+        hbm_gbs = traffic / (launch_ms * 1e-3) / 1e9 if (traffic and launch_ms > 0) else None
+        med = lambda v: v[len(v) // 2] if v else None
         out = {
             "metric": "Mrays/sec (primary+bounce) 1080p OBJ KD-tree scene", "value": value, "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -268,19 +428,33 @@ def main():
             "config": {"workload": "BASELINE configs[2]: Demo 4 bunny.obj (4968 tris, kd-tree) + checker plane + SkyBox sun, "
                                    "1920x1080, MaxRecursion 3, camera (0,0,5)", "rays_per_frame": int(rays_frame),
                        "partition": f"interleaved 32x8 screen tiles over {world} GPU(s)" + (f", RCCL {args.collective} + device assemble" if gather else ""),
-                       "frames_per_call": B, "calls_in_flight": F, "single_frame_latency_ms": lat[len(lat) // 2] if lat else None,
+                       "frames_per_call": B, "calls_in_flight": F,
+                       "single_frame_latency_ms": med(lat), "single_frame_mrays_s": (rays_frame / med(lat) / 1e3) if lat else None,
+                       "ms_per_frame_with_d2h": med(d2h), "mrays_s_with_d2h": (rays_frame / med(d2h) / 1e3) if d2h else None,
                        "frame_checksum": checksum},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(st.launches_trace),
+            # The dominant kernel is divergent fp64 / fp32 VALU work over an L2-resident BVH (0.8 MB): its roof is the vector ALU,
+            # not HBM.  achieved = algorithmic flops of one launch / its duration when it has the GPU to itself.
+            "roofline": {"bound": "valu_fp64", "achieved": tflops, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": tflops / FP64_VALU_PEAK_TFLOPS, "frac_of_unfused_peak": tflops / FP64_VALU_PEAK_UNFUSED_TFLOPS,
+                         "traffic": traffic,
+                         "hbm": {"achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (hbm_gbs / HBM_PEAK_GBS) if hbm_gbs else None,
+                                 "note": "PMC-measured HBM bytes per launch (`traffic`) / avg_launch_ms"},
                          "kernel": "k_trace_quad", "launches_per_call": int(st.launches_trace), "avg_launch_ms": launch_ms,
-                         "algorithmic_bytes_per_call_rank0": int(abytes), "rays_traced_by_kernel_per_call_rank0": int(cst.rays_hard),
+                         "avg_launch_ms_calls_in_flight": launch_ms_overlapped,
+                         "algorithmic_flops_per_call_rank0": int(aflops),
+                         "flop_weights": {"bvh_step_4_boxes_fp32": FLOPS_NODE, "triangle_test_fp64": FLOPS_TRI, "shape_entry_fp64": FLOPS_SHAPE, "hit_record_fp64": FLOPS_RAY},
+                         "counts_per_call_rank0": {"bvh_steps": int(cst.kd_nodes_visited), "triangle_tests": int(cst.kd_tris_tested),
+                                                   "shape_entries": int(cst.shape_tests), "rays": int(cst.rays_hard)},
                          "frames_per_call": B,
                          "pmc": measured_valu(),
-                         "note": "the flattened bunny BVH (~0.8 MB) is L2-resident, so the algorithmic bytes are served by L2 (HBM traffic per "
-                                 "launch is `traffic`, ~25x less) and frac ~ 1 of the HBM peak does not mean HBM-bound: the kernel is bound by VALU "
-                                 "issue (`pmc`: the SIMDs issue VALU instructions 2/3 of the time on this workload, and are issue-stalled most of "
-                                 "the rest); see DESIGN.md"},
+                         "note": "peak = 78.6 TFLOP/s fp64 vector with FMA; the kernels are built with -ffp-contract=off (bit parity with the "
+                                 "non-fused reference), so an instruction is one flop and the usable peak is 39.3 (frac_of_unfused_peak).  "
+                                 "`pmc` is the measured side: share of SIMD cycles issuing VALU x active lanes per instruction.  "
+                                 "avg_launch_ms is a launch alone on the GPU; avg_launch_ms_calls_in_flight is the timed region's regime "
+                                 "(what rocprofv3 --stats of `bench.py --no-extras` averages)"},
         }
+        if cfg4 is not None:
+            out["config4"] = cfg4
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sd)
         print(json.dumps(out), flush=True)

@@ -152,7 +152,7 @@ typedef struct {
     int32_t table;         /* PERLIN/MARBLE: index into perlin_tables (units of 256 bytes) */
     int32_t points_base;   /* WORLEY: first point in worley_points (units of 3 doubles) */
     int32_t divisions;     /* WORLEY */
-    uint32_t octaves;      /* PERLIN/MARBLE (Perlin.h:24), 1..8 */
+    uint32_t octaves;      /* PERLIN/MARBLE (Perlin.h:24), 1..9 (octave i samples at frequency 256 >> i, Perlin.cpp:31) */
     int32_t pad;
     double domain;         /* Noise::m_DomainSize */
     double persistance;    /* Perlin.h:23 */
@@ -275,7 +275,8 @@ const char *rthip_last_error(void);
 int rthip_upload_scene(rthip_ctx *ctx, const rthip_scene_desc *scene);
 /* The same for a scene whose MESH GEOMETRY is the one already uploaded: everything is replaced except the mesh
  * arrays (kd_*, tris, tri_normals, bvh_*), whose pointers in `scene` are ignored (may be null); their counts and
- * the meshes[] table must equal the uploaded ones.  A frame-after-frame caller that only moves nodes, lights,
+ * the meshes[] table must equal the uploaded ones except for normal_mode, which is taken from `scene` (Mesh::NormalMode
+ * is a public field the reference reads live, Scene.cpp:456).  A frame-after-frame caller that only moves nodes, lights,
  * materials or the camera (the Sandbox preview) does not ship hundreds of MB per frame.
  * replaces: Mesh::Compile returning early when nothing was invalidated (Scene.cpp:386-388) */
 int rthip_update_scene(rthip_ctx *ctx, const rthip_scene_desc *scene);

@@ -7,7 +7,7 @@
  * by the non-fused x86-64 baseline build of the reference).
  *
  * Parity: PINNED against oracle/_ref (the genuine reference sources compiled here) — see
- * tests/test_oracle_vs_ref.py and the committed vectors in tests/golden/.
+ * tests/test_oracle.py, tests/test_fuzz.py, tests/test_edge_cases.py and the committed vectors in tests/golden/.
  */
 #define _GNU_SOURCE
 #include "rt_oracle.h"

@@ -1207,6 +1207,7 @@ struct rthip_ctx {
     uint32_t bs_stride = 0, bs_levels = 0;
     uint32_t n_tables = 0;
     bool has_meshes = false;
+    int mesh_without_bvh = -1;  // first mesh that has triangles but no BVH (a caller that supplied only the kd-tree), -1 = none
     std::atomic<int> interrupt{0};
     std::atomic<float> progress{0.f};
     rthip_stats last{};
@@ -1424,7 +1425,7 @@ static int validate_scene(const rthip_scene_desc *s, uint32_t *max_depth, uint32
     if (bg.type < RTHIP_BG_NONE || bg.type > RTHIP_BG_SKYBOX) BAD("background type %d", bg.type);
     if (bg.type == RTHIP_BG_SKYBOX) {
         if (bg.table < 0 || (uint32_t)bg.table >= s->n_perlin_tables) BAD("skybox perlin table out of range");
-        if (bg.sun_light >= (int32_t)s->n_lights) BAD("skybox sun light out of range");
+        if (bg.sun_light < -1 || bg.sun_light >= (int32_t)s->n_lights) BAD("skybox sun light %d out of range (-1 = none)", bg.sun_light);
     }
 #undef BAD
     return 0;
@@ -1447,10 +1448,14 @@ int rthip_update_scene(rthip_ctx *c, const rthip_scene_desc *s) {
     if (!c || !s) return fail(RTHIP_E_INVALID, "rthip_update_scene: null argument");
     if (!c->has_scene) return fail(RTHIP_E_STATE, "rthip_update_scene: no scene uploaded");
     const rthip_scene_desc &u = c->uploaded;
-    if (s->n_meshes != u.n_meshes || s->n_kd_nodes != u.n_kd_nodes || s->n_kd_refs != u.n_kd_refs || s->n_kd_planes != u.n_kd_planes ||
-        s->n_tris != u.n_tris || s->n_bvh_nodes != u.n_bvh_nodes || (s->n_meshes && !s->meshes) ||
-        (s->n_meshes && memcmp(s->meshes, c->mesh_table.data(), sizeof(rthip_mesh) * s->n_meshes) != 0))
-        return fail(RTHIP_E_INVALID, "rthip_update_scene: the mesh table / geometry counts differ from the uploaded scene");
+    bool same = s->n_meshes == u.n_meshes && s->n_kd_nodes == u.n_kd_nodes && s->n_kd_refs == u.n_kd_refs && s->n_kd_planes == u.n_kd_planes &&
+                s->n_tris == u.n_tris && s->n_bvh_nodes == u.n_bvh_nodes && !(s->n_meshes && !s->meshes);
+    for (uint32_t i = 0; same && i < s->n_meshes; i++) {  // everything but normal_mode (Mesh::NormalMode is read live, Scene.cpp:456) must match
+        rthip_mesh a = s->meshes[i];
+        a.normal_mode = c->mesh_table[i].normal_mode;
+        same = memcmp(&a, &c->mesh_table[i], sizeof a) == 0 && (s->meshes[i].normal_mode == 0 || s->meshes[i].normal_mode == 1);
+    }
+    if (!same) return fail(RTHIP_E_INVALID, "rthip_update_scene: the mesh table / geometry counts differ from the uploaded scene");
     return upload_scene(c, s, true);
 }
 
@@ -1471,6 +1476,10 @@ static int upload_scene(rthip_ctx *c, const rthip_scene_desc *s, bool keep_geome
     for (rthip_shape &sh : shapes) roundtrip_bounds(sh, c->mesh_table.data(), c->mesh_roots.data());
     if ((rc = upload(c, c->shapes, shapes.data(), sizeof(rthip_shape) * s->n_shapes))) return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));  // `shapes` is a local
+    if (keep_geometry) {  // the mesh table goes up again: its normal_mode fields may have changed
+        for (uint32_t i = 0; i < s->n_meshes; i++) c->mesh_table[i].normal_mode = s->meshes[i].normal_mode;
+        if ((rc = upload(c, c->meshes, c->mesh_table.data(), sizeof(rthip_mesh) * s->n_meshes))) return rc;
+    }
     if (!keep_geometry) {
         if ((rc = upload(c, c->meshes, s->meshes, sizeof(rthip_mesh) * s->n_meshes))) return rc;
         if ((rc = upload(c, c->kd_nodes, s->kd_nodes, sizeof(rthip_kdnode) * s->n_kd_nodes))) return rc;
@@ -1511,6 +1520,9 @@ static int upload_scene(rthip_ctx *c, const rthip_scene_desc *s, bool keep_geome
     v.n_lights = s->n_lights;
     c->n_tables = s->n_perlin_tables;
     c->has_meshes = s->n_meshes > 0;
+    c->mesh_without_bvh = -1;
+    for (uint32_t i = 0; i < s->n_meshes; i++)
+        if (c->mesh_table[i].tri_count && !c->mesh_table[i].bvh_node_count && c->mesh_without_bvh < 0) c->mesh_without_bvh = (int)i;
     v.bg = s->background;
     c->stack_cap_kd = max_depth + 2;
     c->bvh_depth = max_bvh_depth;
@@ -1550,6 +1562,9 @@ static int render_frame(rthip_ctx *c, const rthip_camera *cam, uint32_t n_frames
     if (n_frames == 0 || n_frames > RTHIP_MAX_BATCH) return fail(RTHIP_E_INVALID, "rthip_render: %u frames per call, limit %d", n_frames, RTHIP_MAX_BATCH);
     if (n_frames > 1 && (d_shape || d_tri)) return fail(RTHIP_E_INVALID, "rthip_render: id images are for single frames");
     if (!c->has_scene) return fail(RTHIP_E_STATE, "rthip_render: no scene uploaded");
+    if (p->accel == 0 && c->mesh_without_bvh >= 0)
+        return fail(RTHIP_E_INVALID, "rthip_render: mesh %d has triangles but no BVH (bvh_node_count = 0): accel = 0 would leave it out of the image; "
+                    "supply bvh_nodes / bvh_tris / bvh_tri_index or render with accel = 1 (kd-tree)", c->mesh_without_bvh);
     if (set_device(c)) return RTHIP_E_HIP;
     c->interrupt.store(0);
     c->progress.store(0.f);

@@ -46,6 +46,29 @@ class Stats(C.Structure):
                 ("ms_easy", C.c_float), ("pad2", C.c_uint32), ("rays_hard", C.c_uint64), ("shape_tests_easy", C.c_uint64)]
 
 
+class Mesh(C.Structure):  # rthip_mesh
+    _fields_ = [("node_base", C.c_uint32), ("node_count", C.c_uint32), ("ref_base", C.c_uint32), ("ref_count", C.c_uint32),
+                ("tri_base", C.c_uint32), ("tri_count", C.c_uint32), ("normal_mode", C.c_int32), ("max_depth", C.c_uint32),
+                ("bvh_node_base", C.c_uint32), ("bvh_node_count", C.c_uint32), ("bvh_tri_base", C.c_uint32), ("bvh_depth", C.c_uint32),
+                ("abs_max", C.c_float), ("pad", C.c_uint32), ("plane_base", C.c_uint32 * 3), ("plane_count", C.c_uint32 * 3)]
+
+
+class Background(C.Structure):  # rthip_background
+    _fields_ = [("type", C.c_int32), ("table", C.c_int32), ("sun_light", C.c_int32), ("pad", C.c_int32),
+                ("color0", C.c_double * 3), ("color1", C.c_double * 3)]
+
+
+class SceneDesc(C.Structure):  # rthip_scene_desc (tests build variants of a flattened scene through this view)
+    _fields_ = [("shapes", C.c_void_p), ("n_shapes", C.c_uint32), ("meshes", C.POINTER(Mesh)), ("n_meshes", C.c_uint32),
+                ("kd_nodes", C.c_void_p), ("n_kd_nodes", C.c_uint64), ("kd_bounds", C.c_void_p),
+                ("kd_refs", C.c_void_p), ("n_kd_refs", C.c_uint64), ("kd_planes", C.c_void_p), ("n_kd_planes", C.c_uint64),
+                ("tris", C.c_void_p), ("n_tris", C.c_uint64), ("tri_normals", C.c_void_p),
+                ("bvh_nodes", C.c_void_p), ("n_bvh_nodes", C.c_uint64), ("bvh_tris", C.c_void_p), ("bvh_tri_index", C.c_void_p),
+                ("materials", C.c_void_p), ("n_materials", C.c_uint32), ("noises", C.c_void_p), ("n_noises", C.c_uint32),
+                ("perlin_tables", C.c_void_p), ("n_perlin_tables", C.c_uint32), ("worley_points", C.c_void_p), ("n_worley_points", C.c_uint64),
+                ("lights", C.c_void_p), ("n_lights", C.c_uint32), ("background", Background)]
+
+
 class RthipError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__(f"rthip error {code}: {msg}")

@@ -41,6 +41,7 @@ def load_host():
         L.rehost_load_obj.argtypes = [C.c_char_p, C.c_char_p, C.c_void_p, C.c_void_p, C.c_int]
         L.rehost_write_ppm.argtypes = [C.c_char_p, C.c_void_p, C.c_int, C.c_int]
         L.rehost_render_moved.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.POINTER(C.c_int)]
+        L.rehost_render_flip_normal_mode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
         _host = sb
     return _host
 
@@ -103,6 +104,18 @@ class HostScene:
         rc = self.L.rehost_render_moved(self.h, C.byref(p), C.c_double(dx), px.ctypes.data_as(C.c_void_p), C.byref(kept))
         if rc != 0:
             raise RuntimeError(f"rehost_render_moved failed ({rc}): " + self.L.rehost_last_error().decode())
+        return px, bool(kept.value)
+
+    def render_flip_normal_mode(self, width, height, max_recursion=3):
+        """Two frames through ONE HipRaytracer; between them Mesh::NormalMode of every mesh flips (Face <-> Vertex).  Returns
+        (pixels of the second frame, whether it kept the device geometry).  The scene keeps the flipped modes."""
+        from .sbapi import RenderParams
+        p = RenderParams(width, height, 0.0, max_recursion, 0, 8, 0)
+        px = np.zeros((height, width), np.uint32)
+        kept = C.c_int(0)
+        rc = self.L.rehost_render_flip_normal_mode(self.h, C.byref(p), px.ctypes.data_as(C.c_void_p), C.byref(kept))
+        if rc != 0:
+            raise RuntimeError(f"rehost_render_flip_normal_mode failed ({rc}): " + self.L.rehost_last_error().decode())
         return px, bool(kept.value)
 
     def last_stats(self):

@@ -140,6 +140,10 @@ struct Flattener {
                 return kGeometryChanged;
             idx = (int32_t)k;
             out.meshes.push_back(previous->meshes[k]);
+            // Mesh::NormalMode is a public field the reference reads live per hit (Scene.cpp:456); changing it does not
+            // invalidate the mesh, so it is not part of the revision: carry the current value (rthip_update_scene
+            // re-uploads the mesh table and accepts a difference in this one field)
+            out.meshes.back().normal_mode = mesh->NormalMode == NormalModes::Vertex ? 1 : 0;
             out.mesh_signature.push_back(previous->mesh_signature[k]);
             mesh_index[mesh] = idx;
             return 0;

@@ -382,6 +382,38 @@ int rehost_render_moved(sb_scene *s, const sb_render_params *p, double dx, uint3
     }
 }
 
+// Two frames through ONE renderer with Mesh::NormalMode of every mesh flipped (Face <-> Vertex) in between: a public field
+// the reference reads live per hit (Scene.cpp:456) and whose change does not invalidate the mesh.  Returns the second
+// frame and whether the geometry stayed on the device.  The scene keeps the flipped modes.
+int rehost_render_flip_normal_mode(sb_scene *s, const sb_render_params *p, uint32_t *pixels_second, int *geometry_kept) {
+    try {
+        HipRaytracer rt(p->width, p->height, p->fovy > 0 ? p->fovy : PI / 4);
+        rt.MaxRecursion = p->max_recursion;
+        rt.Device = s->device;
+        rt.UseReferenceKdTree = s->use_kd != 0;
+        rt.RenderSync(s->scene.get());
+        std::function<void(SceneNode *)> flip = [&](SceneNode *n) {
+            if (auto sh = n->GetComponentOfType<Shape>())
+                if (auto m = dynamic_cast<Mesh *>(sh.get())) m->NormalMode = m->NormalMode == NormalModes::Vertex ? NormalModes::Face : NormalModes::Vertex;
+            for (auto &c : n->GetChildren()) flip(c.get());
+        };
+        flip(s->scene->GetRoot().get());
+        unsigned int *px = rt.RenderSync(s->scene.get());
+        std::memcpy(pixels_second, px, sizeof(uint32_t) * (size_t)p->width * p->height);
+        *geometry_kept = rt.GetLastStats().GeometryKept ? 1 : 0;
+        s->last_stats = rt.GetLastStats();
+        s->compiled = false;
+        s->uploaded = false;
+        return 0;
+    } catch (const DeviceError &e) {
+        g_host_err = e.what();
+        return e.Code;
+    } catch (const std::exception &e) {
+        g_host_err = e.what();
+        return RTHIP_E_INVALID;
+    }
+}
+
 // ---- asynchronous contract of Renderer::Render / GetStatus / Interrupt (Raytracer.h:36-43) ----
 struct rehost_job {
     std::unique_ptr<HipRaytracer> rt;
@@ -441,6 +473,9 @@ int sb_cast_rays(sb_scene *s, int n, const double *o, const double *d, int32_t *
     if (out_tri) std::memcpy(out_tri, tr.data(), sizeof(int32_t) * n);
     return 0;
 }
+// a probe of a noise / material that nothing in the scene references: the flattened scene does not contain it (the tests skip
+// exactly this code and nothing else)
+static const int kNotInScene = -100;
 int sb_noise_sample(sb_scene *s, int noise, int n, const double *p, double *out) {
     // noises that no material references are not part of the flattened scene: attach a probe material
     if (noise < 0 || noise >= (int)s->noises.size()) return -1;
@@ -476,7 +511,7 @@ int sb_noise_sample(sb_scene *s, int noise, int n, const double *p, double *out)
         for (size_t i = 0; i < order.size(); i++)
             if (order[i] == target) flat_index = (int32_t)i;
     }
-    if (flat_index < 0) { g_host_err = "noise is not referenced by any shape material of the scene"; return RTHIP_E_INVALID; }
+    if (flat_index < 0) { g_host_err = "noise is not referenced by any shape material of the scene"; return kNotInScene; }
     rc = rthip_probe_noise(s->ctx, flat_index, (uint32_t)n, p, out);
     if (rc) g_host_err = rthip_last_error();
     return rc;
@@ -489,7 +524,7 @@ int sb_material_eval(sb_scene *s, int mat, int n, const double *p, double *out_c
     int32_t root = -1;
     for (size_t i = 0; i < s->flat->shape_nodes.size(); i++)
         if (s->flat->shape_nodes[i]->GetComponentOfType<Shape>()->Material == s->mats[mat].get()) root = s->flat->shapes[i].material;
-    if (root < 0) { g_host_err = "material is not used by any shape of the scene"; return RTHIP_E_INVALID; }
+    if (root < 0) { g_host_err = "material is not used by any shape of the scene"; return kNotInScene; }
     rc = rthip_probe_material(s->ctx, root, (uint32_t)n, p, out_color, out_absorptance);
     if (rc) g_host_err = rthip_last_error();
     return rc;

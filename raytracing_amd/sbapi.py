@@ -92,6 +92,10 @@ class SbLib:
         return self.lib.sb_impl_name().decode()
 
 
+class NotInScene(LookupError):
+    """a probe of an object the flattened scene does not contain (nothing references it)"""
+
+
 class BuiltScene:
     """A scene instantiated inside one sb_* library."""
 
@@ -149,12 +153,18 @@ class BuiltScene:
 
     def noise_sample(self, noise, p):
         p = _f64(p, 3); out = np.zeros(len(p))
-        assert self.L.sb_noise_sample(self.h, noise, len(p), _dp(p), _dp(out)) == 0
+        rc = self.L.sb_noise_sample(self.h, noise, len(p), _dp(p), _dp(out))
+        if rc == -100:  # the noise exists but no shape's material references it, so the device scene lacks it
+            raise NotInScene(f"noise {noise}")
+        assert rc == 0, rc
         return out
 
     def material_eval(self, mat, p):
         p = _f64(p, 3); col = np.zeros((len(p), 3)); ab = np.zeros(len(p))
-        assert self.L.sb_material_eval(self.h, mat, len(p), _dp(p), _dp(col), _dp(ab)) == 0
+        rc = self.L.sb_material_eval(self.h, mat, len(p), _dp(p), _dp(col), _dp(ab))
+        if rc == -100:
+            raise NotInScene(f"material {mat}")
+        assert rc == 0, rc
         return col, ab
 
     def background_eval(self, d):

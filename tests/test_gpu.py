@@ -9,10 +9,13 @@ import pytest
 
 from conftest import FRAME_CASES, KAT_SCENES, SPARSE_CASES, GOLDEN, assert_frame_parity
 from raytracing_amd import device, host, scenes
+from raytracing_amd.sbapi import NotInScene
 
 pytestmark = pytest.mark.gpu
 
 # scenes whose shading calls libm sin() (Marble): device sin may differ from glibc by an ulp
+# noise kinds reachable from a shape's material in each KAT scene
+KAT_NOISE_KINDS = {"nested": {"perlin", "worley", "checker"}, "cfg2": {"checker", "perlin", "worley", "marble"}, "cfg3": {"checker"}}
 LIBM_SCENES = {"cfg2", "cfg2_dbgC", "demo3", "cfg2_1080p"}
 
 
@@ -114,8 +117,8 @@ def test_known_answers_of_single_device_functions(golden, name):
     for ni, info in sd.noise_info.items():                  # rthip_probe_noise (N0-N4)
         try:
             got = s.noise_sample(ni, p)
-        except AssertionError:
-            continue                                        # noise not referenced by a shape material
+        except NotInScene:
+            continue                                        # noise not referenced by a shape material: not on the device
         used_noises.add(info[0])
         want = k[f"{name}_noise{ni}"]
         if info[0] == "marble":                             # libm sin: 1 ulp
@@ -131,13 +134,15 @@ def test_known_answers_of_single_device_functions(golden, name):
     for mi in range(sd._n["mat"]):                          # rthip_probe_material (M1, M2)
         try:
             mc, ma = s.material_eval(mi, p)
-        except AssertionError:
+        except NotInScene:
             continue
         n_checked += 1
         assert np.abs(mc - k[f"{name}_mat{mi}_color"]).max() < 1e-13 and np.abs(ma - k[f"{name}_mat{mi}_abs"]).max() < 1e-13
         if name != "cfg2":
             assert np.array_equal(mc, k[f"{name}_mat{mi}_color"]) and np.array_equal(ma, k[f"{name}_mat{mi}_abs"])
     assert n_checked > 0
+    # every noise kind the scene's shapes use was probed (a kind silently dropping out would hide a device regression)
+    assert used_noises == KAT_NOISE_KINDS[name], (used_noises, KAT_NOISE_KINDS[name])
 
 
 @pytest.mark.parametrize("name", ["cfg3", "cfg3close", "nested"])
@@ -381,6 +386,52 @@ def test_repeated_renders_keep_the_device_geometry():
         again, kept = hs.render_moved(200, 112, -0.2, max_recursion=3)   # a new renderer: first frame full, second kept
         assert kept and np.array_equal(again, hs.render(200, 112, max_recursion=3)["pixels"])
         assert not np.array_equal(again, second)
+
+
+def test_normal_mode_flipped_between_two_renders_reaches_the_device(oracle_lib):
+    """Mesh::NormalMode is a public field the reference reads live per hit (Scene.cpp:456); flipping it does not invalidate
+    the mesh.  The second Render through the same HipRaytracer must shade with the new mode (and still keep the geometry
+    on the device): equal to a fresh renderer's frame of the flipped scene, different from the first frame."""
+    hs = host.HostScene(scenes.config(3, cam_z=2.5)[0])
+    first = hs.render(200, 112, max_recursion=3)["pixels"]
+    second, kept = hs.render_flip_normal_mode(200, 112, max_recursion=3)
+    assert kept, "a NormalMode change alone must not ship the geometry again"
+    fresh = hs.render(200, 112, max_recursion=3)["pixels"]
+    assert np.array_equal(second, fresh)
+    assert (second != first).sum() > 500, "face normals instead of vertex normals must change the bunny's shading"
+
+
+def test_scene_with_a_mesh_that_has_no_bvh_is_refused_by_the_bvh_path(ctx):
+    """a C-ABI caller that supplies only the kd-tree: accel = 0 would silently leave the mesh out of the image, so the
+    render is refused; accel = 1 (kd-tree everywhere) renders it"""
+    hs = host.HostScene(scenes.config(3, cam_z=2.5)[0])
+    full = C.cast(hs.flatten(), C.POINTER(device.SceneDesc)).contents
+    assert full.n_meshes == 1 and full.meshes[0].tri_count == 4968 and full.meshes[0].bvh_node_count > 0
+    kd_only = device.SceneDesc.from_buffer_copy(full)
+    meshes = (device.Mesh * 1)(device.Mesh.from_buffer_copy(full.meshes[0]))
+    meshes[0].bvh_node_count = 0
+    kd_only.meshes = meshes
+    ctx.upload(C.addressof(kd_only))
+    cam = hs.camera(96, 54)
+    with pytest.raises(device.RthipError) as e:
+        ctx.render(cam, device.make_params(96, 54, 2))
+    assert e.value.code == -1 and "no BVH" in str(e.value)
+    got = ctx.render(cam, device.make_params(96, 54, 2, accel=1), ids=True)
+    ctx.upload(hs.flatten())
+    want = ctx.render(cam, device.make_params(96, 54, 2), ids=True)
+    assert (want["tri"] >= 0).sum() > 300
+    for k in ("pixels", "shape", "tri"):
+        assert np.array_equal(got[k], want[k]), k
+
+
+def test_skybox_sun_index_below_minus_one_is_rejected(ctx):
+    hs = host.HostScene(scenes.config(3, cam_z=2.5)[0])
+    bad = device.SceneDesc.from_buffer_copy(C.cast(hs.flatten(), C.POINTER(device.SceneDesc)).contents)
+    assert bad.background.type == 2
+    bad.background.sun_light = -2
+    with pytest.raises(device.RthipError) as e:
+        ctx.upload(C.addressof(bad))
+    assert e.value.code == -1 and "sun light" in str(e.value)
 
 
 def test_update_scene_rejects_other_geometry(ctx):

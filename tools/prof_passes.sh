@@ -13,4 +13,7 @@ pass spi1 SPI_RA_TMP_STALL_CSN SPI_RA_VGPR_SIMD_FULL_CSN
 pass spi2 SPI_RA_WAVE_SIMD_FULL_CSN SPI_RA_LDS_CU_FULL_CSN
 pass tcc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum
 pass grbm GRBM_GUI_ACTIVE GRBM_COUNT
-for p in sq1 sq2 sqc spi1 spi2 tcc grbm; do python3 tools/prof_report.py $out/$p | grep -E "k_"; done
+# HBM bytes as MI355X_MICROARCH.md prescribes: FETCH_SIZE and WRITE_SIZE in passes of their own (FETCH_SIZE is doubled on gfx950 by prof_summary.py)
+pass fetch FETCH_SIZE
+pass write WRITE_SIZE TCC_EA0_WRREQ_sum
+for p in sq1 sq2 sqc spi1 spi2 tcc grbm fetch write; do python3 tools/prof_report.py $out/$p | grep -E "k_"; done
