@@ -795,9 +795,11 @@ inline void roundtrip_bounds(rthip_shape &sh, const rthip_mesh *meshes, const rt
         s2 = fmax(s2, row);
     }
     double c[3] = {0.0, 0.0, 0.0}, rad2 = 1.0;
+    bool unbounded = sh.type == RTHIP_SHAPE_PLANE;
     if (sh.type == RTHIP_SHAPE_MESH) {
         rad2 = 0.0;
         const rthip_mesh &m = meshes[sh.mesh];
+        if (!m.bvh_node_count && m.tri_count) unbounded = true;  // kd-tree only (accel = 1 callers): no box to bound it with
         if (m.bvh_node_count) {
             const rthip_bvhnode &root = mesh_roots[sh.mesh];
             double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
@@ -821,7 +823,7 @@ inline void roundtrip_bounds(rthip_shape &sh, const rthip_mesh *meshes, const rt
     for (int i = 0; i < 3; i++) sh.bound_c[i] = sh.fwd[4 * i] * c[0] + sh.fwd[4 * i + 1] * c[1] + sh.fwd[4 * i + 2] * c[2] + sh.fwd[4 * i + 3];
     sh.bound_r2 = s2 * rad2 * (1.0 + 1e-9);
     const bool finite = sh.bound_r2 < 1e300 && fabs(sh.bound_c[0]) < 1e300 && fabs(sh.bound_c[1]) < 1e300 && fabs(sh.bound_c[2]) < 1e300;
-    if (sh.type == RTHIP_SHAPE_PLANE || !finite) {  // unbounded, or NaN/inf matrices: never rejects
+    if (unbounded || !finite) {  // unbounded, or NaN/inf matrices: never rejects
         sh.bound_c[0] = sh.bound_c[1] = sh.bound_c[2] = 0.0;
         sh.bound_r2 = 1e300;
     }

@@ -12,6 +12,7 @@
 #include <memory>
 #include <vector>
 
+#include "../mesh_build.hpp"
 #include "math.hpp"
 
 namespace re {
@@ -198,26 +199,9 @@ private:
     real m_D00 = 0, m_D01 = 0, m_D11 = 0, m_InvDen = 0;
 };
 
-// Flattened kd-tree of one mesh, built with the reference's splitting rules (Scene.cpp:18-95) but
-// emitted directly as the compact pre-order arrays the device traverses (include/rthip.h).
-struct KdTreeFlat {
-    struct Node { double split; uint32_t link; uint32_t info; };
-    std::vector<Node> nodes;
-    std::vector<double> bounds;   // 6 per node
-    std::vector<uint32_t> refs;   // leaf triangle indices, pre-order
-    std::vector<uint32_t> depth;  // per node
-    uint32_t max_depth = 0;
-};
-
-// Device-oriented BVH over the same triangles (no reference counterpart; see include/rthip.h).
-struct BvhFlat {
-    struct Child { float lo[3], hi[3]; uint32_t child, pad; };
-    struct Node { Child c[4]; };  // == rthip_bvhnode
-    std::vector<Node> nodes;
-    std::vector<uint32_t> order;  // leaf-order position -> triangle index
-    uint32_t depth = 0;
-    float abs_max = 0.f;
-};
+// flat kd-tree / BVH of one mesh: see mesh_build.hpp (shared with the binding against the genuine reference headers)
+using KdTreeFlat = rtbuild::KdTreeFlat;
+using BvhFlat = rtbuild::BvhFlat;
 
 class Mesh : public Shape {
 public:
