@@ -23,18 +23,9 @@
 
 #include "rt_oracle.h"
 
-using namespace re;
+#include "ref_scene.h"
 
-struct sb_scene {
-    std::shared_ptr<Scene> scene;
-    std::vector<SceneNode *> nodes;  // id -> node (0 = root)
-    std::vector<std::shared_ptr<Material>> mats;
-    std::vector<std::shared_ptr<Noise>> noises;
-    std::vector<std::shared_ptr<Light>> lights;
-    std::vector<int> noise_type;  // 0 checker 1 perlin 2 worley 3 marble
-    std::map<SceneNode *, int> ordinal;
-    bool compiled = false;
-};
+using namespace re;
 
 /* --- ray counter: link-time --wrap of re::Scene::CastRay as seen from Raytracer.o --- */
 static std::atomic<uint64_t> g_flushed{0};
