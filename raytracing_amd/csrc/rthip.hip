@@ -163,7 +163,20 @@ struct Work {
     uint2 *block_stats;         // [2][levels][bs_stride] per workgroup of k_trace_easy / k_shade: (shadow queries, reflected rays) of the frame
     uint32_t bs_stride;
     uint32_t N;
+    // Interrupt() / RenderStatus::Percent at kernel granularity (Raytracer.cpp:91-99, 150-154): `irq` is a word in FINE-GRAINED
+    // device memory (not cached in L2, so a write made while a kernel runs is seen by that kernel) that rthip_interrupt sets
+    // through a side stream; every workgroup reads it when it starts and once per grid-stride iteration and leaves when it is
+    // set.  `stage` is a word in page-locked host memory: workgroup 0 of every kernel stores the index of the stage it begins.
+    const uint32_t *irq;
+    uint32_t *stage;
+    uint32_t stage_base;        // stage index of the current chunk's first kernel
 };
+__device__ __forceinline__ uint32_t irq_load(const Work &w) { return __hip_atomic_load(w.irq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ uint32_t irq_load_wave(const Work &w) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)irq_load(w)); }
+__device__ __forceinline__ void stage_store(const Work &w, uint32_t stage) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(w.stage, stage, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+enum { STAGE_EASY = 0, STAGE_WALK = 1, STAGE_SHADE = 2, STAGES_PER_LEVEL = 3 };
 
 __device__ __forceinline__ uint32_t &level_count(const Work &w, uint32_t level) { return w.counts[(size_t)level * kCounterStride]; }
 __device__ __forceinline__ ColRec &rec_at(const Work &w, uint32_t level, uint32_t i) { return w.rec[(size_t)level * w.N + i]; }
@@ -300,7 +313,11 @@ __global__ __launch_bounds__(kBlock, RT_TRACE_OCC) void k_trace(SceneView sv, Fr
     KdCounters kc = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t max_ray_nodes = 0;
     const long long t_start = COUNT ? clock64() : 0;
+    if (!REDO) stage_store(w, w.stage_base + STAGES_PER_LEVEL * level + STAGE_WALK);
+    uint32_t irq = irq_load(w);
     for (uint32_t base = blockIdx.x * kBlock; base < n; base += gridDim.x * kBlock) {
+        if (__builtin_amdgcn_readfirstlane((int)irq)) break;  // wave-uniform (one address, one load)
+        irq = irq_load(w);  // read again for the next iteration: its latency hides behind this one
         const uint32_t j = base + threadIdx.x;
         const bool in_range = j < n;
         const uint32_t i = in_range ? (REDO ? w.redo[j] : j) : 0u;
@@ -686,6 +703,7 @@ struct ShadeShared {
     uint32_t hard_cnt[kBlock / 64];
     uint32_t hard_base;
     uint32_t part[2][kBlock / 64];
+    uint32_t irq;  // Work::irq as thread 0 read it: the whole workgroup leaves together (its iterations contain barriers)
 };
 template <bool HARD>
 __device__ __forceinline__ void shade_and_spawn(const SceneView &sv, const FrameParams &fp, const Work &w, const uint8_t *tabs,
@@ -911,8 +929,10 @@ __global__ __launch_bounds__(kBlock, RT_EASY_OCC) void k_trace_easy(SceneView sv
                                                                       uint32_t n_tables, uint32_t levels) {
     __shared__ ShadeShared sh;
     const uint32_t n = (level == 0) ? fp.N0 : level_count(w, level);
+    stage_store(w, w.stage_base + STAGES_PER_LEVEL * level + STAGE_EASY);
     if (blockIdx.x * kBlock >= n) return;
     const uint8_t *tabs = reinterpret_cast<const uint8_t *>(lds_dyn);
+    uint32_t irq = threadIdx.x == 0 ? irq_load(w) : 0u;  // (in flight while the tables are staged)
     stage_perlin_tables(sv, n_tables);
     const uint32_t n_shadow = fp.renderer == RTHIP_RENDER_RAYTRACER ? sv.n_lights : 0u;  // DebugRaycaster: closest hit only
     const uint32_t lane = threadIdx.x & 63u;
@@ -920,6 +940,12 @@ __global__ __launch_bounds__(kBlock, RT_EASY_OCC) void k_trace_easy(SceneView sv
     uint32_t shadow_total = 0, spawn_total = 0;
     const long long t_start = COUNT ? clock64() : 0;
     for (uint32_t base = blockIdx.x * kBlock; base < n; base += gridDim.x * kBlock) {
+        // Interrupt(): thread 0 publishes what it read during the previous iteration (the barrier that ends shade_and_spawn
+        // orders the LDS word's reuse), the workgroup leaves together, and the flag is read again for the next iteration
+        if (threadIdx.x == 0) sh.irq = irq;
+        __syncthreads();
+        if (sh.irq) break;
+        if (threadIdx.x == 0) irq = irq_load(w);
         const uint32_t j = base + threadIdx.x;
         bool live = j < n;
         const uint32_t i = live ? j : 0u;
@@ -965,7 +991,11 @@ __global__ __launch_bounds__(kBlock, RT_QUAD_OCC) void k_trace_quad(SceneView sv
     KdCounters kc = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t max_ray_nodes = 0;
     const long long t_start = COUNT ? clock64() : 0;
+    stage_store(w, w.stage_base + STAGES_PER_LEVEL * level + STAGE_WALK);
+    uint32_t irq = irq_load(w);
     for (uint32_t base = blockIdx.x * quad::kRaysPerBlock; base < n; base += gridDim.x * quad::kRaysPerBlock) {
+        if (__builtin_amdgcn_readfirstlane((int)irq)) break;  // Interrupt(): wave-uniform, see Work::irq
+        irq = irq_load(w);
         const uint32_t j = base + g;
         bool live = j < n;
         const uint32_t i = live ? w.hard[j] : 0u;
@@ -1019,11 +1049,17 @@ __global__ __launch_bounds__(kBlock, RT_SHADE_OCC) void k_shade(SceneView sv, Fr
                                                                  uint32_t levels) {
     __shared__ ShadeShared sh;
     const uint32_t n = LIST ? w.hard_count[0] : ((level == 0) ? fp.N0 : level_count(w, level));
+    stage_store(w, w.stage_base + STAGES_PER_LEVEL * level + STAGE_SHADE);
     if (blockIdx.x * kBlock >= n) return;
     const uint8_t *tabs = reinterpret_cast<const uint8_t *>(lds_dyn);
+    uint32_t irq = threadIdx.x == 0 ? irq_load(w) : 0u;
     stage_perlin_tables(sv, n_tables);
     uint32_t shadow_total = 0, spawn_total = 0;
     for (uint32_t base = blockIdx.x * kBlock; base < n; base += gridDim.x * kBlock) {
+        if (threadIdx.x == 0) sh.irq = irq;  // Interrupt(): see k_trace_easy
+        __syncthreads();
+        if (sh.irq) break;
+        if (threadIdx.x == 0) irq = irq_load(w);
         const uint32_t j = base + threadIdx.x;
         uint32_t i = 0;
         HitSlot hs;
@@ -1059,7 +1095,7 @@ __device__ __forceinline__ Col resolve_chain(const Work &w, uint32_t i0, uint32_
         idx[level] = i;
         if (level == max_level) break;
         const uint32_t c = w.child[(size_t)level * w.N + i];
-        if (c == kNoChild) break;
+        if (c >= w.N) break;  // kNoChild; (also: a link an interrupted frame never wrote cannot lead outside the workspace)
         i = c;
         level++;
     }
@@ -1087,7 +1123,9 @@ __global__ __launch_bounds__(kBlock) void k_clear(uint32_t *a, uint32_t na, uint
 __global__ __launch_bounds__(kBlock) void k_resolve(FrameParams fp, Work w, uint32_t *pixels, int32_t *out_shape,
                                                     int32_t *out_tri) {
     uint32_t ps = blockIdx.x * kBlock + threadIdx.x;
+    stage_store(w, w.stage_base + STAGES_PER_LEVEL * (fp.max_rec + 1u));
     if (ps >= fp.n_pix_slots) return;
+    if (irq_load(w)) return;  // Interrupt(): the chains are incomplete, the frame is abandoned (Raytracer.cpp:153)
     uint32_t x, y, frame, part_slot;
     if (!slot_to_pixel(fp, ps, x, y, frame, part_slot)) return;
     Col c;
@@ -1210,6 +1248,15 @@ struct rthip_ctx {
     int mesh_without_bvh = -1;  // first mesh that has triangles but no BVH (a caller that supplied only the kd-tree), -1 = none
     std::atomic<int> interrupt{0};
     std::atomic<float> progress{0.f};
+    // device-visible side of Interrupt() / Percent (see Work::irq): the flag the kernels poll, its side stream, and the stage
+    // word the kernels store to (page-locked host memory)
+    uint32_t *d_irq = nullptr;
+    bool irq_finegrained = false;
+    bool irq_dirty = false;            // d_irq may be non-zero (guarded by irq_mutex)
+    std::mutex irq_mutex;
+    hipStream_t side = nullptr;
+    volatile uint32_t *h_stage = nullptr;
+    std::atomic<uint32_t> stages_total{0};
     rthip_stats last{};
     int count_kd = 0;
     uint32_t last_frames = 1;  // frames of the last render call (statistics are per call)
@@ -1264,6 +1311,19 @@ int rthip_create(int device, rthip_ctx **out) {
         }
     }
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking);
+    if (e == hipSuccess) {  // fine-grained device memory is not cached in L2: a running kernel sees the write of rthip_interrupt
+        if (hipExtMallocWithFlags((void **)&c->d_irq, 256, hipDeviceMallocFinegrained) == hipSuccess && c->d_irq) {
+            c->irq_finegrained = true;
+        } else {  // (then an interrupt is only seen by the kernels launched after it)
+            (void)hipGetLastError();
+            c->d_irq = nullptr;
+            e = hipMalloc((void **)&c->d_irq, 256);
+        }
+    }
+    if (e == hipSuccess) e = hipMemset(c->d_irq, 0, 256);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&c->h_stage, 256, hipHostMallocMapped);
+    if (e == hipSuccess) c->h_stage[0] = 0;
     if (e == hipSuccess) e = hipEventCreate(&c->ev0);
     if (e == hipSuccess) e = hipEventCreate(&c->ev1);
     if (e != hipSuccess) {
@@ -1294,6 +1354,9 @@ int rthip_destroy(rthip_ctx *c) {
     for (DevBuf &b : c->probe) b.release();
     for (auto &g : c->graphs) (void)hipGraphExecDestroy(g.exec);
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
+    if (c->d_irq) (void)hipFree(c->d_irq);
+    if (c->h_stage) (void)hipHostFree((void *)c->h_stage);
+    if (c->side) (void)hipStreamDestroy(c->side);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -1307,10 +1370,24 @@ int rthip_synchronize(rthip_ctx *c) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     return 0;
 }
-float rthip_progress(rthip_ctx *c) { return c ? c->progress.load() : 0.f; }
+float rthip_progress(rthip_ctx *c) {
+    if (!c) return 0.f;
+    const float done = c->progress.load();  // chunks finished (1 once the frame is complete)
+    const uint32_t total = c->stages_total.load();
+    if (done >= 1.f || !total || !c->h_stage) return done;
+    const float staged = (float)c->h_stage[0] / (float)total;  // the stage the device last began, stored by its kernels
+    const float p = staged > done ? staged : done;
+    return p < 0.999f ? p : 0.999f;
+}
 int rthip_interrupt(rthip_ctx *c) {
     if (!c) return fail(RTHIP_E_INVALID, "null context");
+    std::lock_guard<std::mutex> lock(c->irq_mutex);
     c->interrupt.store(1);
+    // tell the kernels that are running or queued: the flag goes to the device on a stream of its own
+    if (c->d_irq && hipSetDevice(c->device) == hipSuccess) {
+        c->irq_dirty = true;
+        if (hipMemsetAsync(c->d_irq, 0xff, sizeof(uint32_t), c->side) == hipSuccess) (void)hipStreamSynchronize(c->side);
+    }
     return 0;
 }
 int rthip_get_stats(rthip_ctx *c, rthip_stats *out) {
@@ -1566,8 +1643,19 @@ static int render_frame(rthip_ctx *c, const rthip_camera *cam, uint32_t n_frames
         return fail(RTHIP_E_INVALID, "rthip_render: mesh %d has triangles but no BVH (bvh_node_count = 0): accel = 0 would leave it out of the image; "
                     "supply bvh_nodes / bvh_tris / bvh_tri_index or render with accel = 1 (kd-tree)", c->mesh_without_bvh);
     if (set_device(c)) return RTHIP_E_HIP;
-    c->interrupt.store(0);
+    {   // a new frame starts uninterrupted (m_Status = { false, false, 0, m_Pixels }, Raytracer.cpp:36); an Interrupt() that
+        // arrives from here on belongs to this frame
+        std::lock_guard<std::mutex> lock(c->irq_mutex);
+        if (c->irq_dirty) {  // the flag of an earlier frame is still up: let that frame's kernels drain, then lower it
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            HIP_TRY(hipMemset(c->d_irq, 0, sizeof(uint32_t)));
+            c->irq_dirty = false;
+        }
+        c->interrupt.store(0);
+    }
     c->progress.store(0.f);
+    c->stages_total.store(0);
+    if (c->h_stage) c->h_stage[0] = 0;
 
     FrameParams fp;
     memset(&fp, 0, sizeof fp);
@@ -1656,6 +1744,11 @@ static int render_frame(rthip_ctx *c, const rthip_camera *cam, uint32_t n_frames
     w.hard = w.redo + N;
     w.bs_stride = bs_stride;
     w.N = (uint32_t)N;
+    w.irq = c->d_irq;
+    w.stage = (uint32_t *)c->h_stage;
+    w.stage_base = 0;
+    const uint32_t stages_per_chunk = STAGES_PER_LEVEL * levels + 1;  // + k_resolve
+    c->stages_total.store(((my_tiles + tiles_per_chunk - 1) / tiles_per_chunk) * stages_per_chunk);
 
     c->sv.accel = p->accel;
     c->stack_cap = c->stack_cap_full;
@@ -1727,6 +1820,7 @@ static int render_frame(rthip_ctx *c, const rthip_camera *cam, uint32_t n_frames
         fp.q0 = q0;
         fp.n_pix_slots = nq * per_tile;
         fp.N0 = fp.n_pix_slots * spp;
+        w.stage_base = (q0 / tiles_per_chunk) * stages_per_chunk + 1;  // (stage 0 = nothing begun yet)
         hipLaunchKernelGGL(k_clear, dim3((kCounterSlots * kCounterStride + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, w.counts,
                            kCounterSlots * kCounterStride, (uint32_t *)nullptr, 0u, (uint32_t *)nullptr, 0u);
         for (uint32_t level = 0; level < levels; level++) {
@@ -1922,7 +2016,10 @@ int rthip_render_batch_device(rthip_ctx *c, const rthip_camera *cams, uint32_t n
     if (!c || !d_pixels) return fail(RTHIP_E_INVALID, "rthip_render_device: null argument");
     int rc = render_frame(c, cams, n_frames, p, (uint32_t *)d_pixels, nullptr, nullptr);
     if (rc) return rc;
-    if (sync) return finish_stats(c, p);
+    if (!sync) return 0;
+    rc = finish_stats(c, p);
+    if (rc) return rc;
+    if (c->interrupt.load()) return fail(RTHIP_E_INTERRUPTED, "rthip_render_device: interrupted");
     return 0;
 }
 
@@ -1930,7 +2027,10 @@ int rthip_render_device_noalloc(rthip_ctx *c, const rthip_camera *cam, const rth
     if (!c || !d_pixels) return fail(RTHIP_E_INVALID, "rthip_render_device_noalloc: null argument");
     int rc = render_frame(c, cam, 1, p, (uint32_t *)d_pixels, nullptr, nullptr, true);
     if (rc) return rc;
-    if (sync) HIP_TRY(hipStreamSynchronize(c->stream));  // (no statistics: reading them back would stage through the runtime)
+    if (sync) {
+        HIP_TRY(hipStreamSynchronize(c->stream));  // (no statistics: reading them back would stage through the runtime)
+        if (c->interrupt.load()) return fail(RTHIP_E_INTERRUPTED, "rthip_render_device_noalloc: interrupted");
+    }
     return 0;
 }
 
@@ -1957,6 +2057,8 @@ int rthip_render(rthip_ctx *c, const rthip_camera *cam, const rthip_params *p, u
     if (rc) return rc;
     rc = finish_stats(c, p);
     if (rc) return rc;
+    // Interrupt() during the frame: its kernels left early and the frame is abandoned (Raytracer.cpp:153); out_pixels untouched
+    if (c->interrupt.load()) return fail(RTHIP_E_INTERRUPTED, "rthip_render: interrupted");
     HIP_TRY(hipMemcpy(out_pixels, d_px, sizeof(uint32_t) * npx, hipMemcpyDeviceToHost));
     if (out_shape) HIP_TRY(hipMemcpy(out_shape, d_sh, sizeof(int32_t) * npx, hipMemcpyDeviceToHost));
     if (out_tri) HIP_TRY(hipMemcpy(out_tri, d_tr, sizeof(int32_t) * npx, hipMemcpyDeviceToHost));

@@ -6,6 +6,7 @@ import time
 
 import numpy as np
 import pytest
+import torch
 
 from conftest import FRAME_CASES, KAT_SCENES, SPARSE_CASES, GOLDEN, assert_frame_parity
 from raytracing_amd import device, host, scenes
@@ -472,14 +473,74 @@ def test_render_contract_async_status_interrupt():
     ref = hs.render(1920, 1080, max_recursion=3)["pixels"]
     assert np.array_equal(px, ref)
     job.close()
-    # interrupt: SSAA frame so that it is long enough to be caught in flight; either way the promise is kept
+    # Interrupt() right after Render(): the promise is kept, with Interruped set (Raytracer.cpp:76-79, 91-94)
     job = host.RenderJob(hs, 1920, 1080, max_recursion=8, aa=1)
     job.interrupt()
     px, st = job.wait()
-    assert st["finished"]
-    if st["interrupted"]:
-        assert st["percent"] == 0.0
+    assert st["finished"] and st["interrupted"] and st["percent"] == 0.0
     job.close()
+    # and the renderer is usable afterwards (a new Render starts uninterrupted, Raytracer.cpp:36)
+    job = host.RenderJob(hs, 320, 180, max_recursion=3)
+    px, st = job.wait()
+    assert st["finished"] and not st["interrupted"] and np.array_equal(px, hs.render(320, 180, max_recursion=3)["pixels"])
+    job.close()
+
+
+def test_interrupt_and_progress_reach_a_frame_that_is_one_workspace_chunk():
+    """Interrupt() / RenderStatus::Percent at kernel granularity (Raytracer.cpp:91-99, 150-154): a 4096x4096 frame is ONE
+    workspace chunk (2^24 level-0 rays) whose ~70 launches are all queued before the first finishes; the device polls the
+    interrupt word per workgroup iteration, so the frame comes back early, and the stage word moves Percent while it runs."""
+    import threading
+    hs = host.HostScene(scenes.config(4, cells=384)[0])
+    ctx = device.Context(0)
+    try:
+        ctx.upload(hs.flatten())
+        w = h = 4096
+        cam, prm = hs.camera(w, h), device.make_params(w, h, 16)
+        fb = torch.zeros(w * h, dtype=torch.int32, device="cuda")
+        ctx.render_device(cam, prm, fb.data_ptr(), sync=True)     # warm-up: workspace allocated
+        seen = []
+        stop = threading.Event()
+
+        def poll():
+            while not stop.is_set():
+                seen.append(ctx.L.rthip_progress(ctx.h))
+                time.sleep(0.0005)
+        t = threading.Thread(target=poll); t.start()
+        t0 = time.perf_counter()
+        ctx.render_device(cam, prm, fb.data_ptr(), sync=True)
+        full = time.perf_counter() - t0
+        stop.set(); t.join()
+        between = [p for p in seen if 0.0 < p < 1.0]
+        assert len(set(between)) >= 3, f"Percent did not move during a {full * 1e3:.1f} ms frame: {sorted(set(seen))[:8]}"
+        assert between == sorted(between), "Percent went backwards"
+        want = fb.clone()
+        # interrupt a quarter of the way in: the call returns RTHIP_E_INTERRUPTED well before a whole frame's time
+        fb.fill_(0x11111111)
+        result = {}
+
+        def render():
+            t1 = time.perf_counter()
+            try:
+                ctx.render_device(cam, prm, fb.data_ptr(), sync=True)
+                result["code"] = 0
+            except device.RthipError as e:
+                result["code"] = e.code
+            result["t"] = time.perf_counter() - t1
+        t = threading.Thread(target=render); t.start()
+        time.sleep(full * 0.25)
+        ti = time.perf_counter()
+        ctx.L.rthip_interrupt(ctx.h)
+        t.join()
+        after = time.perf_counter() - ti
+        assert result["code"] == -4, result
+        assert result["t"] < 0.75 * full and after < 0.4 * full, f"full frame {full * 1e3:.1f} ms, interrupted one {result['t'] * 1e3:.1f} ms, {after * 1e3:.1f} ms after Interrupt()"
+        assert int((fb == 0x11111111).sum().item()) == w * h, "an abandoned frame must not be resolved into the pixel buffer"
+        # the next frame starts uninterrupted and is the same frame as before
+        ctx.render_device(cam, prm, fb.data_ptr(), sync=True)
+        assert torch.equal(fb, want)
+    finally:
+        ctx.close()
 
 
 def test_c_abi_error_reporting(ctx):
