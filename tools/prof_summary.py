@@ -29,7 +29,7 @@ for k, c in sorted(acc.items()):
     lanes = c.get("SQ_THREAD_CYCLES_VALU", 0) / c["SQ_INSTS_VALU"] if c.get("SQ_INSTS_VALU") else 0.0
     # FETCH_SIZE / WRITE_SIZE are in KB; FETCH_SIZE counts a 128-byte request as 64 bytes on gfx950 (MI355X_MICROARCH.md): doubled
     hbm = (c.get("FETCH_SIZE", 0) * 2 + c.get("WRITE_SIZE", 0)) * 1024 / frames if ("FETCH_SIZE" in c or "WRITE_SIZE" in c) else None
-    print(f"| `{k}` | {calls[k] / frames:.0f} | {c['SQ_WAVES'] / frames:,.0f} | {c['SQ_INSTS_VALU'] / frames / 1e6:.1f} | {100 * valu_util:.0f} % | {lanes:.0f} | "
+    print(f"| `{k}` | {calls[k] / frames:.2f} | {c['SQ_WAVES'] / frames:,.0f} | {c['SQ_INSTS_VALU'] / frames / 1e6:.1f} | {100 * valu_util:.0f} % | {lanes:.0f} | "
           f"{100 * c['SQ_WAIT_ANY'] / wc:.0f} % | {100 * c['SQ_WAIT_INST_ANY'] / wc:.0f} % | {100 * c.get('TCC_HIT_sum', 0) / req if req else 0:.0f} % | "
           f"{c.get('TCC_EA0_RDREQ_sum', 0) * 128 / frames / 1e6:.1f} | {(hbm or 0) / 1e6:.1f} | {ms:.3f} |")
     summary[k] = {"valu_issue_util": valu_util, "active_lanes_per_valu_inst": lanes, "wave_time_waiting": c["SQ_WAIT_ANY"] / wc,
