@@ -120,8 +120,9 @@ void Mesh::Compile() {
     // the bounding box starts at (0,0,0)/(0,0,0) and is never reset (Scene.cpp:391-406, Common.h:212)
     // (min / max are exact and order-independent: slices on threads give the same box)
     std::mutex mu;
+    const BoundingBox start = m_BoundingBox;  // read once, before the slices run (they merge into m_BoundingBox under `mu`)
     ParallelSlices(m_Triangles.size(), [&](size_t i0, size_t i1) {
-        BoundingBox bb = m_BoundingBox;
+        BoundingBox bb = start;
         Vector3 &mn = bb.Min, &mx = bb.Max;
         for (size_t i = i0; i < i1; i++) {
             Triangle &t = m_Triangles[i];
