@@ -308,7 +308,7 @@ __global__ __launch_bounds__(kBlock, RT_TRACE_OCC) void k_trace(SceneView sv, Fr
                                                                  uint32_t stack_cap) {
     // LDS: stack_cap child words per lane (no entry parameters: nothing is culled on a pop here)
     KdStack st = make_stack(lds_dyn + threadIdx.x, kBlock, stack_cap, nullptr);
-    const uint32_t n = REDO ? w.redo_count[0] : ((level == 0) ? fp.N0 : level_count(w, level));
+    const uint32_t n = min(w.N, REDO ? w.redo_count[0] : ((level == 0) ? fp.N0 : level_count(w, level)));  // (lists are bounded by the workspace)
     const uint32_t n_shadow = fp.renderer == RTHIP_RENDER_RAYTRACER ? sv.n_lights : 0u;  // DebugRaycaster: closest hit only
     KdCounters kc = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t max_ray_nodes = 0;
@@ -744,16 +744,20 @@ __device__ __forceinline__ void shade_and_spawn(const SceneView &sv, const Frame
     if (HARD && is_hard) {  // listed for the quad kernel (which traces it) and k_shade (which shades it)
         uint32_t slot = sh.hard_base + (uint32_t)__popcll(hmask & ((1ull << lane) - 1ull));
         for (uint32_t k = 0; k < wid; k++) slot += sh.hard_cnt[k];
-        w.hard[slot] = i;
-        w.pend[slot] = *analytic;
+        if (slot < w.N) {  // (always, unless the list counter was not zero when the level began)
+            w.hard[slot] = i;
+            w.pend[slot] = *analytic;
+        }
         if (level == 0) store_ray(w, 0, i, o, d, 0u);  // k_shade needs the direction (background, reflection)
     }
     uint32_t child = kNoChild;
     if (so.spawn) {
         uint32_t j = sh.block_base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
         for (uint32_t k = 0; k < wid; k++) j += sh.wave_cnt[k];
-        store_ray(w, level + 1, j, so.child_o, so.child_d, i);
-        child = j;
+        if (j < w.N) {  // (always, unless the level counter was not zero when the frame began)
+            store_ray(w, level + 1, j, so.child_o, so.child_d, i);
+            child = j;
+        }
         spawn_total++;
     }
     if (have) w.child[(size_t)level * w.N + i] = child;  // the chain k_resolve folds back to front
@@ -928,7 +932,7 @@ template <bool COUNT>
 __global__ __launch_bounds__(kBlock, RT_EASY_OCC) void k_trace_easy(SceneView sv, FrameParams fp, Work w, uint32_t level,
                                                                       uint32_t n_tables, uint32_t levels) {
     __shared__ ShadeShared sh;
-    const uint32_t n = (level == 0) ? fp.N0 : level_count(w, level);
+    const uint32_t n = min(w.N, (level == 0) ? fp.N0 : level_count(w, level));
     stage_store(w, w.stage_base + STAGES_PER_LEVEL * level + STAGE_EASY);
     if (blockIdx.x * kBlock >= n) return;
     const uint8_t *tabs = reinterpret_cast<const uint8_t *>(lds_dyn);
@@ -986,7 +990,7 @@ __global__ __launch_bounds__(kBlock, RT_QUAD_OCC) void k_trace_quad(SceneView sv
     quad::Stack qs;
     qs.cap = stack_cap;
     qs.e = reinterpret_cast<uint2 *>(lds_dyn) + g * (stack_cap + 1u);
-    const uint32_t n = w.hard_count[0];
+    const uint32_t n = min(w.N, w.hard_count[0]);
     const uint32_t n_shadow = fp.renderer == RTHIP_RENDER_RAYTRACER ? sv.n_lights : 0u;  // DebugRaycaster: closest hit only
     KdCounters kc = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t max_ray_nodes = 0;
@@ -1019,7 +1023,8 @@ __global__ __launch_bounds__(kBlock, RT_QUAD_OCC) void k_trace_quad(SceneView sv
         if (!live || q != 0) continue;
         if (COUNT && kc.nodes - nodes_before > max_ray_nodes) max_ray_nodes = kc.nodes - nodes_before;
         if (!done) {
-            w.redo[atomicAdd(&w.redo_count[0], 1u)] = i;
+            const uint32_t slot = atomicAdd(&w.redo_count[0], 1u);
+            if (slot < w.N) w.redo[slot] = i;
             continue;
         }
         if (hit_shape < 0) {  // a miss: the whole record
@@ -1048,7 +1053,7 @@ template <bool LIST>
 __global__ __launch_bounds__(kBlock, RT_SHADE_OCC) void k_shade(SceneView sv, FrameParams fp, Work w, uint32_t level, uint32_t n_tables,
                                                                  uint32_t levels) {
     __shared__ ShadeShared sh;
-    const uint32_t n = LIST ? w.hard_count[0] : ((level == 0) ? fp.N0 : level_count(w, level));
+    const uint32_t n = min(w.N, LIST ? w.hard_count[0] : ((level == 0) ? fp.N0 : level_count(w, level)));
     stage_store(w, w.stage_base + STAGES_PER_LEVEL * level + STAGE_SHADE);
     if (blockIdx.x * kBlock >= n) return;
     const uint8_t *tabs = reinterpret_cast<const uint8_t *>(lds_dyn);
@@ -1109,14 +1114,22 @@ __device__ __forceinline__ Col resolve_chain(const Work &w, uint32_t i0, uint32_
     return c;
 }
 
-// The per-frame counters and statistics are cleared by ONE small kernel, not by hipMemsetAsync: a memset node of a
-// replayed HIP graph stopped clearing its buffer once a second graph of the same context had been instantiated
-// (ROCm 7.2; seen as garbage ray statistics), kernel nodes are not affected.
+// Everything the frame path clears or fills on the device goes through these two small KERNELS, never through
+// hipMemsetAsync.  With hipMemsetAsync for the per-frame counters (memset nodes once the launches are captured into a graph),
+// ROCm 7.2 keeps stream order as long as calls are synchronous or a single context queues them (tools/micro/graph_memset.hip and
+// tools/gpu_graph_memset.py find nothing wrong there), but with several contexts queueing asynchronous calls of two shapes - the
+// bench's regime - the counters are not zero when a frame starts (round 1 saw it as garbage ray statistics): list reservations
+// then run past the workspace and the GPU takes a memory fault (seen once in round 2 with the memsets switched back in).  A
+// kernel node or launch is ordered like every other kernel of the stream.  The list writers below also bound their indices by
+// the workspace size, so that a counter that is wrong for whatever reason can cost a frame but not the GPU.
 __global__ __launch_bounds__(kBlock) void k_clear(uint32_t *a, uint32_t na, uint32_t *b, uint32_t nb, uint32_t *c, uint32_t nc) {
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i < na) a[i] = 0u;
     if (i < nb) b[i] = 0u;
     if (i < nc) c[i] = 0u;
+}
+__global__ __launch_bounds__(kBlock) void k_fill(uint32_t *a, size_t n, uint32_t value) {
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) a[i] = value;
 }
 
 // chains -> pixels (Common.cpp:275-282); SSAA: result += c * (1.0f/9.0f), clamped (Raytracer.cpp:139)
@@ -2050,7 +2063,7 @@ int rthip_render(rthip_ctx *c, const rthip_camera *cam, const rthip_params *p, u
     if (p->part_count > 1) {  // pixels of other parts keep the caller's contents
         HIP_TRY(hipMemcpyAsync(d_px, out_pixels, sizeof(uint32_t) * npx, hipMemcpyHostToDevice, c->stream));
     }
-    if (ids) HIP_TRY(hipMemsetAsync(d_sh, 0xff, sizeof(int32_t) * 2 * npx, c->stream));
+    if (ids) hipLaunchKernelGGL(k_fill, dim3(1024), dim3(kBlock), 0, c->stream, (uint32_t *)d_sh, 2 * npx, 0xffffffffu);  // -1 = no hit
     rthip_params pf = *p;
     pf.layout = 0;
     rc = render_frame(c, cam, 1, &pf, d_px, d_sh, d_tr);
