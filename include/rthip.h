@@ -342,6 +342,32 @@ float rthip_progress(rthip_ctx *ctx);
 int rthip_interrupt(rthip_ctx *ctx);
 
 int rthip_get_stats(rthip_ctx *ctx, rthip_stats *out);
+/* After an ASYNCHRONOUS rthip_render_device / rthip_render_batch_device (sync = 0): waits for the context's stream, gathers
+ * the statistics of that call (params = the ones it was made with) into *out (nullable) and returns RTHIP_E_INTERRUPTED if
+ * rthip_interrupt arrived during it.  What the synchronous calls do at their end. */
+int rthip_collect_stats(rthip_ctx *ctx, const rthip_params *params, rthip_stats *out);
+
+/* ---- several GPUs of one node from ONE process ----
+ * replaces: the NumThreads std::async workers of AbstractRaycaster::Render (Raytracer.cpp:52-87) - the reference's only
+ * parallel decomposition - by one context + stream per GPU driven from the calling thread.  The screen is
+ * split into interleaved tiles (tile t -> devices[t % n]); every device renders its share into a tile-compact buffer in its own
+ * HBM; the parts are moved to devices[0] over xGMI with RCCL (ncclCommInitAll, grouped ncclSend / ncclRecv; librccl is opened
+ * with dlopen when the first multi-GPU renderer is created) and assembled there; one D2H copy returns the frame.  The image is
+ * bit-identical to the single-GPU image.  Repeated ordinals (the same GPU several times: how a one-GPU box rehearses the path)
+ * and hosts without librccl use peer / device-to-device copies instead; RTHIP_MULTI_TRANSPORT=copy|rccl forces either. */
+typedef struct rthip_multi rthip_multi;
+int rthip_multi_create(const int *devices, int n_devices, rthip_multi **out);
+int rthip_multi_destroy(rthip_multi *m);
+int rthip_multi_device_count(rthip_multi *m);
+rthip_ctx *rthip_multi_context(rthip_multi *m, int i);   /* the context of devices[i] (owned by m): host allocations, probes, statistics */
+const char *rthip_multi_transport(rthip_multi *m);   /* "RCCL ncclSend/ncclRecv" or "peer copies" */
+/* the scene is replicated on every device; keep_geometry != 0: rthip_update_scene semantics */
+int rthip_multi_upload_scene(rthip_multi *m, const rthip_scene_desc *scene, int keep_geometry);
+/* one frame into host memory (width*height uint32, as rthip_render); params->part_* / layout are set by the call;
+ * out_stats (nullable): ray counts summed over the devices, ms_total = the slowest device's */
+int rthip_multi_render(rthip_multi *m, const rthip_camera *cam, const rthip_params *params, uint32_t *out_pixels, rthip_stats *out_stats);
+float rthip_multi_progress(rthip_multi *m);
+int rthip_multi_interrupt(rthip_multi *m);
 
 /* Known-answer probes: run single device functions on n inputs (device parity tests of the
  * S1/P1/P2/T2/T4, N0-N4, M1/M2, B1/B2 and R4 rows of SURVEY.md §8a against the oracle). */

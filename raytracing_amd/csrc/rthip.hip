@@ -45,6 +45,7 @@ static int fail(int code, const char *fmt, ...) {
     g_err = buf;
     return code;
 }
+extern "C" void rthip_set_last_error(const char *msg) { g_err = msg ? msg : ""; }  // for the library's other translation units
 #define HIP_TRY(expr)                                                                              \
     do {                                                                                           \
         hipError_t e_ = (expr);                                                                    \
@@ -2018,6 +2019,16 @@ static int finish_stats(rthip_ctx *c, const rthip_params *p) {
     c->last.ms_trace = sum;
     c->last.ms_easy = sum_easy;
     c->progress.store(1.f);
+    return 0;
+}
+
+int rthip_collect_stats(rthip_ctx *c, const rthip_params *p, rthip_stats *out) {
+    if (!c || !p) return fail(RTHIP_E_INVALID, "rthip_collect_stats: null argument");
+    if (set_device(c)) return RTHIP_E_HIP;
+    int rc = finish_stats(c, p);
+    if (rc) return rc;
+    if (out) *out = c->last;
+    if (c->interrupt.load()) return fail(RTHIP_E_INTERRUPTED, "rthip_render_device: interrupted");
     return 0;
 }
 

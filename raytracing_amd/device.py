@@ -19,7 +19,9 @@ SYMBOLS = ["rthip_create", "rthip_destroy", "rthip_last_error", "rthip_upload_sc
            "rthip_get_stats", "rthip_probe_cast", "rthip_probe_noise", "rthip_probe_material",
            "rthip_probe_background", "rthip_probe_raycast", "rthip_probe_arith", "rthip_version",
            "rthip_part_pixels", "rthip_assemble", "rthip_render_batch_device", "rthip_assemble_batch", "rthip_host_alloc",
-           "rthip_host_free", "rthip_update_scene", "rthip_render_device_noalloc"]
+           "rthip_host_free", "rthip_update_scene", "rthip_render_device_noalloc", "rthip_collect_stats", "rthip_multi_create",
+           "rthip_multi_destroy", "rthip_multi_device_count", "rthip_multi_context", "rthip_multi_transport", "rthip_multi_upload_scene",
+           "rthip_multi_render", "rthip_multi_progress", "rthip_multi_interrupt"]
 MAX_BATCH = 16  # RTHIP_MAX_BATCH
 
 
@@ -104,6 +106,19 @@ def lib():
     L.rthip_render.argtypes = [vp, C.POINTER(Camera), C.POINTER(Params), c_u32p, c_i32p, c_i32p]
     L.rthip_render_device.argtypes = [vp, C.POINTER(Camera), C.POINTER(Params), vp, C.c_int]
     L.rthip_render_device_noalloc.argtypes = [vp, C.POINTER(Camera), C.POINTER(Params), vp, C.c_int]
+    L.rthip_collect_stats.argtypes = [vp, C.POINTER(Params), C.POINTER(Stats)]
+    L.rthip_multi_create.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(vp)]
+    L.rthip_multi_destroy.argtypes = [vp]
+    L.rthip_multi_device_count.argtypes = [vp]
+    L.rthip_multi_context.argtypes = [vp, C.c_int]
+    L.rthip_multi_context.restype = vp
+    L.rthip_multi_transport.argtypes = [vp]
+    L.rthip_multi_transport.restype = C.c_char_p
+    L.rthip_multi_upload_scene.argtypes = [vp, vp, C.c_int]
+    L.rthip_multi_render.argtypes = [vp, C.POINTER(Camera), C.POINTER(Params), c_u32p, C.POINTER(Stats)]
+    L.rthip_multi_progress.argtypes = [vp]
+    L.rthip_multi_progress.restype = C.c_float
+    L.rthip_multi_interrupt.argtypes = [vp]
     L.rthip_part_pixels.argtypes = [C.POINTER(Params)]
     L.rthip_part_pixels.restype = C.c_uint64
     L.rthip_assemble.argtypes = [vp, C.POINTER(Params), vp, vp, C.c_int]
@@ -258,3 +273,44 @@ class Context:
         col = np.zeros((len(o), 3))
         self._check(self.L.rthip_probe_raycast(self.h, max_recursion, len(o), _dp(o), _dp(d), _dp(col)))
         return col
+
+
+class MultiContext:
+    """rthip_multi: several GPUs of the node driven from this one process (interleaved tiles, RCCL / peer-copy gather to the
+    first device, device assemble)."""
+
+    def __init__(self, devices):
+        self.L = lib()
+        h = C.c_void_p()
+        arr = (C.c_int * len(devices))(*devices)
+        rc = self.L.rthip_multi_create(arr, len(devices), C.byref(h))
+        if rc != 0:
+            raise RthipError(rc, self.L.rthip_last_error().decode())
+        self.h = h
+
+    def _check(self, rc):
+        if rc != 0:
+            raise RthipError(rc, self.L.rthip_last_error().decode())
+
+    def transport(self):
+        return self.L.rthip_multi_transport(self.h).decode()
+
+    def upload(self, desc_ptr, keep_geometry=False):
+        self._check(self.L.rthip_multi_upload_scene(self.h, desc_ptr, int(keep_geometry)))
+
+    def render(self, cam, params):
+        px = np.zeros((params.height, params.width), np.uint32)
+        st = Stats()
+        self._check(self.L.rthip_multi_render(self.h, C.byref(cam), C.byref(params), px.ctypes.data_as(c_u32p), C.byref(st)))
+        return {"pixels": px, "rays": st.rays_primary + st.rays_shadow + st.rays_reflect, "stats": st}
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.rthip_multi_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

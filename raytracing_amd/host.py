@@ -25,6 +25,7 @@ def load_host():
         L.rehost_flatten.argtypes = [C.c_void_p]; L.rehost_flatten.restype = C.c_void_p
         L.rehost_camera.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.POINTER(device.Camera)]
         L.rehost_set_device.argtypes = [C.c_void_p, C.c_int]; L.rehost_set_device.restype = None
+        L.rehost_set_devices.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.c_int]; L.rehost_set_devices.restype = None
         L.rehost_set_accel.argtypes = [C.c_void_p, C.c_int]; L.rehost_set_accel.restype = None
         L.rehost_shape_count.argtypes = [C.c_void_p]
         L.rehost_shape_ordinal.argtypes = [C.c_void_p, C.c_int]
@@ -70,6 +71,11 @@ class HostScene:
         self.h = self.built.h
         self.L.rehost_set_device(self.h, device_index)
         return self
+
+    def set_devices(self, devices):
+        """HipRaytracer::Devices: render() splits the frame over these GPUs from this one process (rthip_multi_*)"""
+        arr = (C.c_int * len(devices))(*devices)
+        self.L.rehost_set_devices(self.h, arr, len(devices))
 
     def set_accel(self, use_reference_kd):
         self.L.rehost_set_accel(self.h, int(bool(use_reference_kd)))

@@ -6,6 +6,7 @@
 // be called from another thread while rendering.  Device failures are delivered as
 // re::DeviceError through the promise — there is no CPU fallback.
 #include <chrono>
+#include <cstring>
 #include <thread>
 
 #include "flatten.hpp"
@@ -32,14 +33,16 @@ HipRaytracer::HipRaytracer(unsigned int w, unsigned int h, real fovY) : Abstract
 HipRaytracer::~HipRaytracer() {
     {   // a detached render thread still uses *this: wait for it
         std::unique_lock<std::mutex> lock(m_Mutex);
-        if (m_Busy && m_Ctx) rthip_interrupt(m_Ctx);
+        if (m_Busy && m_Multi) rthip_multi_interrupt(m_Multi);
+        else if (m_Busy && m_Ctx) rthip_interrupt(m_Ctx);
         m_Idle.wait(lock, [this] { return !m_Busy; });
     }
     if (m_Ctx && m_PixelsPinned) {  // m_Pixels is page-locked memory of the library, not the base class's new[]
         (void)rthip_host_free(m_Ctx, m_Pixels);
         m_Pixels = nullptr;
     }
-    if (m_Ctx) rthip_destroy(m_Ctx);
+    if (m_Multi) rthip_multi_destroy(m_Multi);  // owns m_Ctx
+    else if (m_Ctx) rthip_destroy(m_Ctx);
 }
 
 Color HipRaytracer::Raycast(Scene *, const Ray &) {
@@ -49,7 +52,8 @@ Color HipRaytracer::Raycast(Scene *, const Ray &) {
 void HipRaytracer::Interrupt() {
     m_Interrupted = true;  // Raytracer.cpp:91-94
     std::lock_guard<std::mutex> lock(m_Mutex);
-    if (m_Busy && m_Ctx) rthip_interrupt(m_Ctx);
+    if (m_Busy && m_Multi) rthip_multi_interrupt(m_Multi);
+    else if (m_Busy && m_Ctx) rthip_interrupt(m_Ctx);
 }
 
 Renderer::RenderStatus HipRaytracer::GetStatus() {
@@ -58,11 +62,13 @@ Renderer::RenderStatus HipRaytracer::GetStatus() {
     s.Interruped = m_Interrupted;
     s.Pixels = m_Pixels;
     rthip_ctx *ctx;
+    rthip_multi *multi;
     {
         std::lock_guard<std::mutex> lock(m_Mutex);
         ctx = m_Ctx;
+        multi = m_Multi;
     }
-    s.Percent = s.Finished ? (s.Interruped ? 0.f : 1.f) : (ctx ? rthip_progress(ctx) : 0.f);
+    s.Percent = s.Finished ? (s.Interruped ? 0.f : 1.f) : (multi ? rthip_multi_progress(multi) : (ctx ? rthip_progress(ctx) : 0.f));
     return s;
 }
 
@@ -85,7 +91,12 @@ void HipRaytracer::Render(Scene *scene, std::promise<RenderStatus> p) {
         // a failure is reported through the promise by the render thread.
         std::lock_guard<std::mutex> lock(m_Mutex);
         if (!m_Ctx) {
-            m_CreateRc = rthip_create(Device, &m_Ctx);
+            if (Devices.size() > 1) {
+                m_CreateRc = rthip_multi_create(Devices.data(), (int)Devices.size(), &m_Multi);
+                if (!m_CreateRc) m_Ctx = rthip_multi_context(m_Multi, 0);
+            } else {
+                m_CreateRc = rthip_create(Devices.empty() ? Device : Devices[0], &m_Ctx);
+            }
             m_CreateErr = m_CreateRc ? rthip_last_error() : "";
             void *pinned = nullptr;
             if (!m_CreateRc && rthip_host_alloc(m_Ctx, sizeof(unsigned int) * m_ViewWidth * m_ViewHeight, &pinned) == 0) {
@@ -122,7 +133,8 @@ void HipRaytracer::RenderThread(Scene *scene, std::promise<RenderStatus> p) {
             }
         }
         if (!rc) {
-            rc = flat.geometry_kept ? rthip_update_scene(m_Ctx, &flat.desc) : rthip_upload_scene(m_Ctx, &flat.desc);
+            if (m_Multi) rc = rthip_multi_upload_scene(m_Multi, &flat.desc, flat.geometry_kept ? 1 : 0);
+            else rc = flat.geometry_kept ? rthip_update_scene(m_Ctx, &flat.desc) : rthip_upload_scene(m_Ctx, &flat.desc);
             if (rc) err = rthip_last_error();
             if (!rc) {
                 stats.GeometryKept = flat.geometry_kept;
@@ -149,15 +161,17 @@ void HipRaytracer::RenderThread(Scene *scene, std::promise<RenderStatus> p) {
             prm.tile_h = TileHeight;
             prm.layout = 0;
             prm.accel = UseReferenceKdTree ? 1 : 0;
-            rc = rthip_render(m_Ctx, &cam, &prm, m_Pixels, nullptr, nullptr);
+            rthip_stats st;
+            std::memset(&st, 0, sizeof st);
+            if (m_Multi) rc = rthip_multi_render(m_Multi, &cam, &prm, m_Pixels, &st);
+            else rc = rthip_render(m_Ctx, &cam, &prm, m_Pixels, nullptr, nullptr);
             if (rc == RTHIP_E_INTERRUPTED) {
                 m_Interrupted = true;
                 rc = 0;
             } else if (rc) {
                 err = rthip_last_error();
             } else {
-                rthip_stats st;
-                if (rthip_get_stats(m_Ctx, &st) == 0) {
+                if (m_Multi || rthip_get_stats(m_Ctx, &st) == 0) {
                     stats.RaysPrimary = st.rays_primary;
                     stats.RaysShadow = st.rays_shadow;
                     stats.RaysReflect = st.rays_reflect;

@@ -11,10 +11,12 @@
 #include <mutex>
 #include <stdexcept>
 #include <string>
+#include <vector>
 
 #include "scene.hpp"
 
 struct rthip_ctx;
+struct rthip_multi;
 
 namespace re {
 
@@ -76,6 +78,10 @@ public:
     unsigned int MaxRecursion = 3;
     // additive knobs
     int Device = 0;                         // HIP device ordinal of this process
+    // more than one entry: the frame is split over these GPUs of the node from this one process (interleaved tiles, parts
+    // gathered to Devices[0] over xGMI with RCCL, rthip_multi_* in include/rthip.h) - the device-side counterpart of
+    // NumThreads (Raytracer.h:74).  Set before the first Render.
+    std::vector<int> Devices;
     unsigned int PartIndex = 0, PartCount = 1;  // interleaved-tile share rendered by this process
     unsigned int TileWidth = 32, TileHeight = 8;
     bool UseReferenceKdTree = false;        // traverse the reference's kd-tree instead of the BVH (same image)
@@ -93,7 +99,8 @@ protected:
     virtual int RendererKind() const { return 0; }  // RTHIP_RENDER_RAYTRACER
 private:
     void RenderThread(Scene *scene, std::promise<RenderStatus> p);
-    rthip_ctx *m_Ctx = nullptr;
+    rthip_ctx *m_Ctx = nullptr;      // single device; with Devices.size() > 1: the first device's context (owned by m_Multi)
+    rthip_multi *m_Multi = nullptr;
     bool m_PixelsPinned = false;
     std::unique_ptr<FlatScene> m_Flat;  // the scene as last uploaded, geometry arrays released (see RenderThread)
     int m_CreateRc = 0;

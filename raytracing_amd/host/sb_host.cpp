@@ -29,6 +29,7 @@ struct sb_scene {
     bool uploaded = false;
     int device = 0;
     int use_kd = 0;
+    std::vector<int> devices;  // more than one: HipRaytracer::Devices (the frame is split over these GPUs)
     HipRenderStats last_stats;
     ~sb_scene() { if (ctx) rthip_destroy(ctx); }
 };
@@ -273,6 +274,7 @@ int rehost_camera(sb_scene *s, int width, int height, double fovy, rthip_camera 
     return 0;
 }
 void rehost_set_device(sb_scene *s, int device) { s->device = device; }
+void rehost_set_devices(sb_scene *s, const int *devices, int n) { s->devices.assign(devices, devices + (n > 0 ? n : 0)); }
 void rehost_set_accel(sb_scene *s, int use_reference_kd) { s->use_kd = use_reference_kd; }
 int rehost_shape_count(sb_scene *s) { return ensure_flat(s) ? -1 : (int)s->flat->shapes.size(); }
 // shape ordinal of a node id (or -1)
@@ -307,6 +309,7 @@ int sb_render(sb_scene *s, const sb_render_params *p, uint32_t *pixels, int32_t 
         rt->MaxRecursion = p->max_recursion;
         rt->NumThreads = p->num_threads;
         rt->Device = s->device;
+        rt->Devices = s->devices;
         rt->UseReferenceKdTree = s->use_kd != 0;
         rt->Antialiasing = p->aa_mode == 1 ? AbstractRaycaster::AAMode::SSAA : AbstractRaycaster::AAMode::None;
         unsigned int *px = rt->RenderSync(s->scene.get());
