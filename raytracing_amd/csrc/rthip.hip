@@ -31,6 +31,7 @@
 #include <vector>
 
 #include "rt_core.hpp"
+#include "rthip_bvh.hpp"
 
 using namespace rtc;
 
@@ -380,7 +381,7 @@ template <int CTRL> __device__ __forceinline__ double dpp(double v) {
     return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 // The quad's stack of pending children in LDS: 8-byte entries {child word, entry parameter}, sized by the
-// tree (3 * depth + 1 entries can never overflow: a step pushes at most three children and descends one
+// tree (3 * (depth + 1) entries can never overflow: a step pushes at most three children and descends one
 // level), plus one dummy entry that absorbs the writes of lanes with nothing to push.
 struct Stack {
     uint2 *e;
@@ -1253,6 +1254,7 @@ struct rthip_ctx {
     rthip_scene_desc uploaded{};             // the last uploaded description (its counts; the pointers are the caller's)
     std::vector<rthip_mesh> mesh_table;      // host copies for rthip_update_scene
     std::vector<rthip_bvhnode> mesh_roots;
+    std::vector<uint8_t> mesh_device_bvh;    // mesh i's BVH was built on the device (its bvh_* fields in mesh_table are the library's)
     uint32_t stack_cap = 1;
     // frame workspace
     DevBuf rec, child, rays, counts, stats, block_stats, ids, pixels_tmp, ids_out, hits, redo, pend, probe[8];
@@ -1528,11 +1530,18 @@ static int upload(rthip_ctx *c, DevBuf &b, const void *src, size_t bytes) {
     return 0;
 }
 
-static int upload_scene(rthip_ctx *c, const rthip_scene_desc *s, bool keep_geometry);
+static int upload_scene(rthip_ctx *c, const rthip_scene_desc *s, bool keep_geometry, bool build_bvh = false);
 
 int rthip_upload_scene(rthip_ctx *c, const rthip_scene_desc *s) {
     if (!c || !s) return fail(RTHIP_E_INVALID, "rthip_upload_scene: null argument");
     return upload_scene(c, s, false);
+}
+
+int rthip_upload_scene_ex(rthip_ctx *c, const rthip_scene_desc *s, uint32_t flags) {
+    if (!c || !s) return fail(RTHIP_E_INVALID, "rthip_upload_scene_ex: null argument");
+    if (flags & ~(uint32_t)(RTHIP_UPLOAD_BUILD_BVH | RTHIP_UPLOAD_KEEP_GEOMETRY)) return fail(RTHIP_E_INVALID, "rthip_upload_scene_ex: unknown flags 0x%x", flags);
+    if (flags & RTHIP_UPLOAD_KEEP_GEOMETRY) return rthip_update_scene(c, s);
+    return upload_scene(c, s, false, (flags & RTHIP_UPLOAD_BUILD_BVH) != 0);
 }
 
 int rthip_update_scene(rthip_ctx *c, const rthip_scene_desc *s) {
@@ -1544,45 +1553,107 @@ int rthip_update_scene(rthip_ctx *c, const rthip_scene_desc *s) {
     for (uint32_t i = 0; same && i < s->n_meshes; i++) {  // everything but normal_mode (Mesh::NormalMode is read live, Scene.cpp:456) must match
         rthip_mesh a = s->meshes[i];
         a.normal_mode = c->mesh_table[i].normal_mode;
+        if (c->mesh_device_bvh[i] && a.bvh_node_count == 0) {  // the BVH this library built at upload: its fields are not the caller's
+            const rthip_mesh &t = c->mesh_table[i];
+            a.bvh_node_base = t.bvh_node_base; a.bvh_node_count = t.bvh_node_count; a.bvh_tri_base = t.bvh_tri_base;
+            a.bvh_depth = t.bvh_depth; a.abs_max = t.abs_max;
+        }
         same = memcmp(&a, &c->mesh_table[i], sizeof a) == 0 && (s->meshes[i].normal_mode == 0 || s->meshes[i].normal_mode == 1);
     }
     if (!same) return fail(RTHIP_E_INVALID, "rthip_update_scene: the mesh table / geometry counts differ from the uploaded scene");
     return upload_scene(c, s, true);
 }
 
-static int upload_scene(rthip_ctx *c, const rthip_scene_desc *s, bool keep_geometry) {
+static int upload_scene(rthip_ctx *c, const rthip_scene_desc *s, bool keep_geometry, bool build_bvh) {
     uint32_t max_depth = 0, max_bvh_depth = 0;
     int rc = validate_scene(s, &max_depth, &max_bvh_depth, keep_geometry);
     if (rc) return rc;
     if (set_device(c)) return RTHIP_E_HIP;
     c->has_scene = false;
     HIP_TRY(hipStreamSynchronize(c->stream));
-    if (!keep_geometry) {  // host copies of what an update needs later: the mesh table and every mesh's BVH root
-        c->mesh_table.assign(s->meshes, s->meshes + s->n_meshes);
-        c->mesh_roots.assign(s->n_meshes, rthip_bvhnode{});
-        for (uint32_t i = 0; i < s->n_meshes; i++)
-            if (s->meshes[i].bvh_node_count) c->mesh_roots[i] = s->bvh_nodes[s->meshes[i].bvh_node_base];
-    }
-    std::vector<rthip_shape> shapes(s->shapes, s->shapes + s->n_shapes);
-    for (rthip_shape &sh : shapes) roundtrip_bounds(sh, c->mesh_table.data(), c->mesh_roots.data());
-    if ((rc = upload(c, c->shapes, shapes.data(), sizeof(rthip_shape) * s->n_shapes))) return rc;
-    HIP_TRY(hipStreamSynchronize(c->stream));  // `shapes` is a local
     if (keep_geometry) {  // the mesh table goes up again: its normal_mode fields may have changed
         for (uint32_t i = 0; i < s->n_meshes; i++) c->mesh_table[i].normal_mode = s->meshes[i].normal_mode;
         if ((rc = upload(c, c->meshes, c->mesh_table.data(), sizeof(rthip_mesh) * s->n_meshes))) return rc;
     }
     if (!keep_geometry) {
-        if ((rc = upload(c, c->meshes, s->meshes, sizeof(rthip_mesh) * s->n_meshes))) return rc;
+        // host copies of what an update needs later: the mesh table and every mesh's BVH root
+        c->mesh_table.assign(s->meshes, s->meshes + s->n_meshes);
+        c->mesh_roots.assign(s->n_meshes, rthip_bvhnode{});
+        c->mesh_device_bvh.assign(s->n_meshes, 0);
+        bool any_device = false;
+        for (uint32_t i = 0; i < s->n_meshes; i++) {
+            if (s->meshes[i].bvh_node_count) c->mesh_roots[i] = s->bvh_nodes[s->meshes[i].bvh_node_base];
+            else if (build_bvh && s->meshes[i].tri_count) any_device = c->mesh_device_bvh[i] = 1;
+        }
         if ((rc = upload(c, c->kd_nodes, s->kd_nodes, sizeof(rthip_kdnode) * s->n_kd_nodes))) return rc;
         if ((rc = upload(c, c->kd_bounds, s->kd_bounds, sizeof(double) * 6 * s->n_kd_nodes))) return rc;
         if ((rc = upload(c, c->kd_refs, s->kd_refs, sizeof(uint32_t) * s->n_kd_refs))) return rc;
         if ((rc = upload(c, c->tris, s->tris, sizeof(rthip_tri) * s->n_tris))) return rc;
         if ((rc = upload(c, c->tri_normals, s->tri_normals, sizeof(double) * 9 * s->n_tris))) return rc;
         if ((rc = upload(c, c->kd_planes, s->kd_planes, sizeof(double) * s->n_kd_planes))) return rc;
-        if ((rc = upload(c, c->bvh_nodes, s->bvh_nodes, sizeof(rthip_bvhnode) * s->n_bvh_nodes))) return rc;
-        if ((rc = upload(c, c->bvh_tris, s->bvh_tris, s->n_bvh_nodes ? sizeof(rthip_tri) * s->n_tris : 0))) return rc;
-        if ((rc = upload(c, c->bvh_index, s->bvh_tri_index, s->n_bvh_nodes ? sizeof(uint32_t) * s->n_tris : 0))) return rc;
+        if (!any_device) {
+            if ((rc = upload(c, c->bvh_nodes, s->bvh_nodes, sizeof(rthip_bvhnode) * s->n_bvh_nodes))) return rc;
+            if ((rc = upload(c, c->bvh_tris, s->bvh_tris, s->n_bvh_nodes ? sizeof(rthip_tri) * s->n_tris : 0))) return rc;
+            if ((rc = upload(c, c->bvh_index, s->bvh_tri_index, s->n_bvh_nodes ? sizeof(uint32_t) * s->n_tris : 0))) return rc;
+        } else {
+            // RTHIP_UPLOAD_BUILD_BVH: the meshes that came without a BVH get theirs built here, on the device, from the
+            // triangle records just uploaded (rthip_bvh.hip).  On the device every mesh's leaf-order arrays sit at its
+            // tri_base; the nodes of the caller's BVHs come first, the library's are appended.
+            if (c->bvh_tris.ensure(sizeof(rthip_tri) * s->n_tris)) return RTHIP_E_HIP;
+            if (c->bvh_index.ensure(sizeof(uint32_t) * s->n_tris)) return RTHIP_E_HIP;
+            struct Built { rthip_bvhnode *nodes; rthip_device_bvh_info info; };
+            std::vector<Built> built(s->n_meshes, Built{nullptr, {}});
+            auto release = [&]() { for (Built &b : built) if (b.nodes) (void)hipFree(b.nodes); };
+            uint64_t total = s->n_bvh_nodes;
+            for (uint32_t i = 0; i < s->n_meshes; i++) {
+                rthip_mesh &m = c->mesh_table[i];
+                rthip_tri *leaf_tris = (rthip_tri *)c->bvh_tris.p + m.tri_base;
+                uint32_t *leaf_index = (uint32_t *)c->bvh_index.p + m.tri_base;
+                if (!c->mesh_device_bvh[i]) {
+                    if (m.bvh_node_count) {
+                        hipError_t e = hipMemcpyAsync(leaf_tris, s->bvh_tris + m.bvh_tri_base, sizeof(rthip_tri) * m.tri_count, hipMemcpyHostToDevice, c->stream);
+                        if (e == hipSuccess) e = hipMemcpyAsync(leaf_index, s->bvh_tri_index + m.bvh_tri_base, sizeof(uint32_t) * m.tri_count, hipMemcpyHostToDevice, c->stream);
+                        if (e != hipSuccess) { release(); return fail(RTHIP_E_HIP, "rthip_upload_scene: %s", hipGetErrorString(e)); }
+                        m.bvh_tri_base = m.tri_base;
+                    }
+                    continue;
+                }
+                char msg[256] = "";
+                rc = rthip_bvh_build_device(c->stream, (const rthip_tri *)c->tris.p + m.tri_base, m.tri_count, leaf_tris, leaf_index, &built[i].nodes,
+                                            &built[i].info, msg, sizeof msg);
+                if (rc) { release(); return fail(rc, "rthip_upload_scene: mesh %u: %s", i, msg); }
+                total += built[i].info.n_nodes;
+            }
+            if (total > 0xfffffff0ull) { release(); return fail(RTHIP_E_UNSUPPORTED, "rthip_upload_scene: more than 2^32 BVH nodes"); }
+            if (c->bvh_nodes.ensure(sizeof(rthip_bvhnode) * total)) { release(); return RTHIP_E_HIP; }
+            hipError_t e = hipSuccess;
+            if (s->n_bvh_nodes) e = hipMemcpyAsync(c->bvh_nodes.p, s->bvh_nodes, sizeof(rthip_bvhnode) * s->n_bvh_nodes, hipMemcpyHostToDevice, c->stream);
+            uint64_t base = s->n_bvh_nodes;
+            for (uint32_t i = 0; i < s->n_meshes && e == hipSuccess; i++) {
+                if (!c->mesh_device_bvh[i]) continue;
+                rthip_mesh &m = c->mesh_table[i];
+                const rthip_device_bvh_info &info = built[i].info;
+                e = hipMemcpyAsync((rthip_bvhnode *)c->bvh_nodes.p + base, built[i].nodes, sizeof(rthip_bvhnode) * info.n_nodes, hipMemcpyDeviceToDevice, c->stream);
+                m.bvh_node_base = (uint32_t)base;
+                m.bvh_node_count = info.n_nodes;
+                m.bvh_tri_base = m.tri_base;
+                m.bvh_depth = info.depth;
+                m.abs_max = info.abs_max;
+                c->mesh_roots[i] = info.root;
+                base += info.n_nodes;
+            }
+            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+            release();
+            if (e != hipSuccess) return fail(RTHIP_E_HIP, "rthip_upload_scene: %s", hipGetErrorString(e));
+        }
+        if ((rc = upload(c, c->meshes, c->mesh_table.data(), sizeof(rthip_mesh) * s->n_meshes))) return rc;
     }
+    max_bvh_depth = 0;  // from the table the device holds (it carries the depths of the BVHs built here)
+    for (const rthip_mesh &m : c->mesh_table) max_bvh_depth = m.bvh_depth > max_bvh_depth ? m.bvh_depth : max_bvh_depth;
+    std::vector<rthip_shape> shapes(s->shapes, s->shapes + s->n_shapes);
+    for (rthip_shape &sh : shapes) roundtrip_bounds(sh, c->mesh_table.data(), c->mesh_roots.data());
+    if ((rc = upload(c, c->shapes, shapes.data(), sizeof(rthip_shape) * s->n_shapes))) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));  // `shapes` is a local
     if ((rc = upload(c, c->materials, s->materials, sizeof(rthip_matop) * s->n_materials))) return rc;
     if ((rc = upload(c, c->noises, s->noises, sizeof(rthip_noise) * s->n_noises))) return rc;
     if ((rc = upload(c, c->perlin, s->perlin_tables, (size_t)256 * s->n_perlin_tables))) return rc;
@@ -1617,7 +1688,7 @@ static int upload_scene(rthip_ctx *c, const rthip_scene_desc *s, bool keep_geome
     v.bg = s->background;
     c->stack_cap_kd = max_depth + 2;
     c->bvh_depth = max_bvh_depth;
-    c->stack_cap_bvh = 3 * max_bvh_depth + 2;  // one ray per lane over the 4-wide BVH: up to three pending children per level
+    c->stack_cap_bvh = 3 * (max_bvh_depth + 1) + 1;  // one ray per lane over the 4-wide BVH: up to three pending children per level, the root's included
     c->stack_cap_full = (max_depth + 2 > c->stack_cap_bvh ? max_depth + 2 : c->stack_cap_bvh);  // degenerate rays walk the kd-tree
     c->stack_cap = c->stack_cap_full;
     c->uploaded = *s;  // counts only are read later (rthip_update_scene)
@@ -1775,7 +1846,9 @@ static int render_frame(rthip_ctx *c, const rthip_camera *cam, uint32_t n_frames
         HIP_TRY(hipFuncSetAttribute((const void *)k_trace<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     }
     // hot kernel: one short stack per quad (child word + entry parameter per entry); deeper rays overflow into the redo list
-    const uint32_t quad_cap = 3 * c->bvh_depth + 1;  // cannot overflow, see quad::Stack
+    // cannot overflow, see quad::Stack: the deepest node is bvh_depth levels below the root, so a path makes bvh_depth + 1 steps
+    // of at most three pushes (3 * depth + 1 was one level short: a mesh whose BVH is a lone root overflowed with two pushes)
+    const uint32_t quad_cap = 3 * (c->bvh_depth + 1);
     const size_t lds_quad = (size_t)quad::kRaysPerBlock * (quad_cap + 1) * sizeof(uint2);
     if (lds_quad > 64 * 1024) {
         HIP_TRY(hipFuncSetAttribute((const void *)k_trace_quad<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_quad));
@@ -2234,6 +2307,23 @@ int rthip_probe_raycast(rthip_ctx *c, uint32_t max_recursion, uint32_t n, const 
     HIP_TRY(hipGetLastError());
     if ((rc = probe_out(c, color, pc, v))) return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+int rthip_probe_bvh(rthip_ctx *c, uint32_t mesh, rthip_mesh *out_mesh, rthip_bvhnode *nodes, uint64_t cap_nodes, uint32_t *tri_index, uint64_t cap_tris) {
+    if (!c) return fail(RTHIP_E_INVALID, "null context");
+    if (!c->has_scene) return fail(RTHIP_E_STATE, "no scene uploaded");
+    if (mesh >= c->mesh_table.size()) return fail(RTHIP_E_INVALID, "rthip_probe_bvh: mesh %u not in [0,%zu)", mesh, c->mesh_table.size());
+    if (set_device(c)) return RTHIP_E_HIP;
+    const rthip_mesh &m = c->mesh_table[mesh];
+    if (out_mesh) *out_mesh = m;
+    if (nodes) {
+        if (cap_nodes < m.bvh_node_count) return fail(RTHIP_E_INVALID, "rthip_probe_bvh: %u nodes, room for %llu", m.bvh_node_count, (unsigned long long)cap_nodes);
+        if (m.bvh_node_count) HIP_TRY(hipMemcpy(nodes, (const rthip_bvhnode *)c->bvh_nodes.p + m.bvh_node_base, sizeof(rthip_bvhnode) * m.bvh_node_count, hipMemcpyDeviceToHost));
+    }
+    if (tri_index) {
+        if (cap_tris < m.tri_count) return fail(RTHIP_E_INVALID, "rthip_probe_bvh: %u triangles, room for %llu", m.tri_count, (unsigned long long)cap_tris);
+        if (m.tri_count && m.bvh_node_count) HIP_TRY(hipMemcpy(tri_index, (const uint32_t *)c->bvh_index.p + m.bvh_tri_base, sizeof(uint32_t) * m.tri_count, hipMemcpyDeviceToHost));
+    }
     return 0;
 }
 int rthip_probe_arith(rthip_ctx *c, int32_t op, uint32_t n, const double *a, const double *b, double *out) {

@@ -184,10 +184,10 @@ rthip_ctx *rthip_multi_context(rthip_multi *m, int i) { return (m && i >= 0 && i
 const char *rthip_multi_transport(rthip_multi *m) { return m ? m->transport.c_str() : ""; }
 
 // the scene is replicated: every device gets its own copy (<= 2.5 GB at config 5)
-int rthip_multi_upload_scene(rthip_multi *m, const rthip_scene_desc *scene, int keep_geometry) {
+int rthip_multi_upload_scene(rthip_multi *m, const rthip_scene_desc *scene, uint32_t flags) {
     if (!m || !scene) return mfail(RTHIP_E_INVALID, "rthip_multi_upload_scene: null argument");
     for (rthip_ctx *c : m->ctx) {
-        int rc = keep_geometry ? rthip_update_scene(c, scene) : rthip_upload_scene(c, scene);
+        int rc = rthip_upload_scene_ex(c, scene, flags);
         if (rc) return rc;
     }
     return 0;

@@ -21,8 +21,9 @@ SYMBOLS = ["rthip_create", "rthip_destroy", "rthip_last_error", "rthip_upload_sc
            "rthip_part_pixels", "rthip_assemble", "rthip_render_batch_device", "rthip_assemble_batch", "rthip_host_alloc",
            "rthip_host_free", "rthip_update_scene", "rthip_render_device_noalloc", "rthip_collect_stats", "rthip_multi_create",
            "rthip_multi_destroy", "rthip_multi_device_count", "rthip_multi_context", "rthip_multi_transport", "rthip_multi_upload_scene",
-           "rthip_multi_render", "rthip_multi_progress", "rthip_multi_interrupt"]
+           "rthip_multi_render", "rthip_multi_progress", "rthip_multi_interrupt", "rthip_upload_scene_ex", "rthip_probe_bvh"]
 MAX_BATCH = 16  # RTHIP_MAX_BATCH
+UPLOAD_BUILD_BVH, UPLOAD_KEEP_GEOMETRY = 1, 2  # RTHIP_UPLOAD_*
 
 
 class Camera(C.Structure):
@@ -106,6 +107,8 @@ def lib():
     L.rthip_render.argtypes = [vp, C.POINTER(Camera), C.POINTER(Params), c_u32p, c_i32p, c_i32p]
     L.rthip_render_device.argtypes = [vp, C.POINTER(Camera), C.POINTER(Params), vp, C.c_int]
     L.rthip_render_device_noalloc.argtypes = [vp, C.POINTER(Camera), C.POINTER(Params), vp, C.c_int]
+    L.rthip_upload_scene_ex.argtypes = [vp, vp, C.c_uint32]
+    L.rthip_probe_bvh.argtypes = [vp, C.c_uint32, C.POINTER(Mesh), vp, C.c_uint64, vp, C.c_uint64]
     L.rthip_collect_stats.argtypes = [vp, C.POINTER(Params), C.POINTER(Stats)]
     L.rthip_multi_create.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(vp)]
     L.rthip_multi_destroy.argtypes = [vp]
@@ -114,7 +117,7 @@ def lib():
     L.rthip_multi_context.restype = vp
     L.rthip_multi_transport.argtypes = [vp]
     L.rthip_multi_transport.restype = C.c_char_p
-    L.rthip_multi_upload_scene.argtypes = [vp, vp, C.c_int]
+    L.rthip_multi_upload_scene.argtypes = [vp, vp, C.c_uint32]
     L.rthip_multi_render.argtypes = [vp, C.POINTER(Camera), C.POINTER(Params), c_u32p, C.POINTER(Stats)]
     L.rthip_multi_progress.argtypes = [vp]
     L.rthip_multi_progress.restype = C.c_float
@@ -179,9 +182,20 @@ class Context:
         except Exception:
             pass
 
-    def upload(self, desc_ptr):
-        """desc_ptr: `const rthip_scene_desc*` (e.g. from host.HostScene.flatten())."""
-        self._check(self.L.rthip_upload_scene(self.h, desc_ptr))
+    def upload(self, desc_ptr, build_bvh=True):
+        """desc_ptr: `const rthip_scene_desc*` (e.g. from host.HostScene.flatten()).  build_bvh: meshes that come without a BVH
+        (the host library leaves the big ones to the device) get theirs built on the device (RTHIP_UPLOAD_BUILD_BVH)."""
+        self._check(self.L.rthip_upload_scene_ex(self.h, desc_ptr, UPLOAD_BUILD_BVH if build_bvh else 0))
+
+    def bvh(self, mesh=0):
+        """(mesh-table entry, nodes as a structured array [n]['c'][4], leaf-order triangle indices) of a mesh's BVH on the device"""
+        m = Mesh()
+        self._check(self.L.rthip_probe_bvh(self.h, mesh, C.byref(m), None, 0, None, 0))
+        child = np.dtype([("lo", "<f4", 3), ("hi", "<f4", 3), ("child", "<u4"), ("pad", "<u4")])
+        nodes = np.zeros(m.bvh_node_count, dtype=np.dtype([("c", child, 4)]))
+        index = np.zeros(m.tri_count, np.uint32)
+        self._check(self.L.rthip_probe_bvh(self.h, mesh, None, nodes.ctypes.data_as(C.c_void_p), len(nodes), index.ctypes.data_as(C.c_void_p), len(index)))
+        return m, nodes, index
 
     def update(self, desc_ptr):
         """like upload() for a scene whose mesh geometry is the one already uploaded (rthip_update_scene)"""
@@ -296,7 +310,7 @@ class MultiContext:
         return self.L.rthip_multi_transport(self.h).decode()
 
     def upload(self, desc_ptr, keep_geometry=False):
-        self._check(self.L.rthip_multi_upload_scene(self.h, desc_ptr, int(keep_geometry)))
+        self._check(self.L.rthip_multi_upload_scene(self.h, desc_ptr, UPLOAD_KEEP_GEOMETRY if keep_geometry else UPLOAD_BUILD_BVH))
 
     def render(self, cam, params):
         px = np.zeros((params.height, params.width), np.uint32)

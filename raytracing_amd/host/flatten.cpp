@@ -189,8 +189,10 @@ struct Flattener {
             out.kd_planes.insert(out.kd_planes.end(), planes.begin(), planes.end());
         }
         const BvhFlat &bvh = mesh->GetBvh();
+        const bool device_bvh = mesh->BvhBuiltOnDevice() && bvh.nodes.empty() && !tris.empty();  // left to RTHIP_UPLOAD_BUILD_BVH
+        if (device_bvh) out.needs_device_bvh = true;
         if (bvh.depth > RTHIP_BVH_MAX_DEPTH) return Unsupported("BVH deeper than the device stack");
-        if (bvh.order.size() != tris.size() || tris.size() > RTHIP_BVH_FIRST_MASK) return Unsupported("mesh too large for the BVH leaf encoding");
+        if ((!device_bvh && bvh.order.size() != tris.size()) || tris.size() > RTHIP_BVH_FIRST_MASK) return Unsupported("mesh too large for the BVH leaf encoding");
         m.bvh_node_base = (uint32_t)out.bvh_nodes.size();
         m.bvh_node_count = (uint32_t)bvh.nodes.size();
         m.bvh_tri_base = (uint32_t)out.bvh_tris.size();
@@ -211,15 +213,19 @@ struct Flattener {
             return r;
         };
         const size_t n = tris.size(), b0 = out.bvh_tris.size(), t0 = out.tris.size();
-        out.bvh_tris.resize(b0 + n);
-        out.bvh_tri_index.resize(b0 + n);
+        if (!device_bvh) {
+            out.bvh_tris.resize(b0 + n);
+            out.bvh_tri_index.resize(b0 + n);
+        }
         out.tris.resize(t0 + n);
         out.tri_normals.resize(9 * (t0 + n));
         ParallelSlices(n, [&](size_t i0, size_t i1) {
             for (size_t i = i0; i < i1; i++) {
-                const uint32_t ti = bvh.order[i];
-                out.bvh_tris[b0 + i] = pack(tris[ti]);
-                out.bvh_tri_index[b0 + i] = ti;
+                if (!device_bvh) {
+                    const uint32_t ti = bvh.order[i];
+                    out.bvh_tris[b0 + i] = pack(tris[ti]);
+                    out.bvh_tri_index[b0 + i] = ti;
+                }
                 const Triangle &t = tris[i];
                 out.tris[t0 + i] = pack(t);
                 double *nn = &out.tri_normals[9 * (t0 + i)];
@@ -335,6 +341,7 @@ struct Flattener {
         if (previous) {
             if (out.meshes.size() != previous->meshes.size()) return kGeometryChanged;
             out.geometry_kept = true;
+            out.needs_device_bvh = previous->needs_device_bvh;
             const rthip_scene_desc &pd = previous->desc;
             d.kd_nodes = nullptr; d.kd_bounds = nullptr; d.kd_refs = nullptr; d.kd_planes = nullptr; d.tris = nullptr;
             d.tri_normals = nullptr; d.bvh_nodes = nullptr; d.bvh_tris = nullptr; d.bvh_tri_index = nullptr;
@@ -359,6 +366,12 @@ int FlattenScene(Scene *scene, FlatScene &out, std::string &error, const FlatSce
     std::memset(&out.desc, 0, sizeof out.desc);
     Flattener f{scene, out, error, {}, {}, {}, {}, nullptr};
     return f.Run();
+}
+
+void ForceHostBvhEverywhere(SceneNode *node) {
+    if (auto shape = node->GetComponentOfType<Shape>())
+        if (auto mesh = dynamic_cast<Mesh *>(shape.get())) mesh->BuildHostBvh();
+    for (auto &child : node->GetChildren()) ForceHostBvhEverywhere(child.get());
 }
 
 void FlatScene::ReleaseGeometry() {

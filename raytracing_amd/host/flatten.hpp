@@ -30,6 +30,7 @@ struct FlatScene {
     std::vector<SceneNode *> shape_nodes;  // pre-order shape ordinal -> node
     // (mesh, Mesh::GetRevision()) in meshes[] order: identifies the geometry arrays above
     std::vector<std::pair<const Mesh *, uint64_t>> mesh_signature;
+    bool needs_device_bvh = false;  // some mesh comes without a BVH: upload with RTHIP_UPLOAD_BUILD_BVH (see Mesh::BvhBuiltOnDevice)
     bool geometry_kept = false;  // flattened against `previous`: geometry arrays empty, desc pointers null, counts kept
 
     // drops the geometry arrays (they can be hundreds of MB) but keeps what a later FlattenScene(..., this) needs
@@ -44,6 +45,13 @@ struct FlatScene {
 int FlattenScene(Scene *scene, FlatScene &out, std::string &error, const FlatScene *previous = nullptr);
 
 // Camera basis of AbstractRaycaster::CreateScreenRay (Raytracer.cpp:102-110) computed once per frame.
+// upload flags (rthip_upload_scene_ex) that go with a flattened scene
+inline uint32_t UploadFlags(const FlatScene &f) {
+    return f.geometry_kept ? RTHIP_UPLOAD_KEEP_GEOMETRY : (f.needs_device_bvh ? RTHIP_UPLOAD_BUILD_BVH : 0u);
+}
+// every mesh below `node` gets a host-built BVH from now on (after the device refused to build one: deeper than its stacks)
+void ForceHostBvhEverywhere(SceneNode *node);
+
 void MakeCamera(const Scene *scene, size_t width, size_t height, real fovY, rthip_camera &cam);
 
 }  // namespace re

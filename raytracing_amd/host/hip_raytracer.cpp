@@ -133,9 +133,16 @@ void HipRaytracer::RenderThread(Scene *scene, std::promise<RenderStatus> p) {
             }
         }
         if (!rc) {
-            if (m_Multi) rc = rthip_multi_upload_scene(m_Multi, &flat.desc, flat.geometry_kept ? 1 : 0);
-            else rc = flat.geometry_kept ? rthip_update_scene(m_Ctx, &flat.desc) : rthip_upload_scene(m_Ctx, &flat.desc);
-            if (rc) err = rthip_last_error();
+            auto upload = [&]() { return m_Multi ? rthip_multi_upload_scene(m_Multi, &flat.desc, UploadFlags(flat)) : rthip_upload_scene_ex(m_Ctx, &flat.desc, UploadFlags(flat)); };
+            rc = upload();
+            if (rc == RTHIP_E_UNSUPPORTED && flat.needs_device_bvh && !flat.geometry_kept) {
+                // the device would not build a BVH (deeper than its traversal stacks): build them on the host after all
+                ForceHostBvhEverywhere(scene->GetRoot().get());
+                flat = FlatScene();
+                rc = FlattenScene(scene, flat, err, nullptr);
+                if (!rc) rc = upload();
+            }
+            if (rc && err.empty()) err = rthip_last_error();
             if (!rc) {
                 stats.GeometryKept = flat.geometry_kept;
                 flat.ReleaseGeometry();

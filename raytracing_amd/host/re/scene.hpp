@@ -212,7 +212,13 @@ public:
     void Invalidate() { m_Invalidated = true; }
     const std::vector<Triangle> &GetTriangles() const { return m_Triangles; }  // additive
     const KdTreeFlat &GetKdTree() const { return m_KdTree; }                    // additive
-    const BvhFlat &GetBvh() const { return m_Bvh; }                             // additive
+    const BvhFlat &GetBvh() const { return m_Bvh; }                             // additive (empty when BvhBuiltOnDevice())
+    // additive: meshes of at least DeviceBvhMinTriangles() triangles (2^18; env RE_BVH_DEVICE_MIN_TRIS, 0 = never) do not
+    // build the 4-wide BVH in Compile(): the device builds it at upload.  ForceHostBvh / BuildHostBvh() bring it back.
+    bool ForceHostBvh = false;
+    bool BvhBuiltOnDevice() const;
+    void BuildHostBvh();
+    static size_t DeviceBvhMinTriangles();
     const BoundingBox &GetBounds() const { return m_BoundingBox; }              // additive
     // additive: changes every time Compile() rebuilds the acceleration structures (process-wide unique), so a renderer
     // can tell that the geometry it has already flattened and uploaded is still the current one

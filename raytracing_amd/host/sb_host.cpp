@@ -51,7 +51,7 @@ static int ensure_device(sb_scene *s) {
     if (rc) return rc;
     if (!s->ctx && (rc = rthip_create(s->device, &s->ctx))) { g_host_err = rthip_last_error(); return rc; }
     if (!s->uploaded) {
-        if ((rc = rthip_upload_scene(s->ctx, &s->flat->desc))) { g_host_err = rthip_last_error(); return rc; }
+        if ((rc = rthip_upload_scene_ex(s->ctx, &s->flat->desc, UploadFlags(*s->flat)))) { g_host_err = rthip_last_error(); return rc; }
         s->uploaded = true;
     }
     return 0;

@@ -100,11 +100,6 @@ void Triangle::Update() {
     m_InvDen = 1.0 / (m_D00 * m_D11 - m_D01 * m_D01);
 }
 
-Triangle &Mesh::AddTriangle() {
-    m_Triangles.emplace_back();
-    return m_Triangles.back();
-}
-
 namespace {
 // the mesh's triangles as the builders of mesh_build.hpp read them
 struct MirrorTriView {
@@ -114,6 +109,29 @@ struct MirrorTriView {
     double V(uint32_t tri, int vertex, unsigned axis) const { return t[tri].Vertices[vertex][axis]; }
 };
 }  // namespace
+
+size_t Mesh::DeviceBvhMinTriangles() {
+    if (const char *e = std::getenv("RE_BVH_DEVICE_MIN_TRIS")) {
+        const long long v = atoll(e);
+        return v <= 0 ? (size_t)-1 : (size_t)v;
+    }
+    return (size_t)1 << 18;
+}
+bool Mesh::BvhBuiltOnDevice() const { return !ForceHostBvh && m_Triangles.size() >= DeviceBvhMinTriangles(); }
+void Mesh::BuildHostBvh() {
+    ForceHostBvh = true;
+    if (m_Invalidated || !m_Bvh.nodes.empty() || m_Triangles.empty()) return;  // not compiled yet (Compile will build it) / already there
+    const MirrorTriView view{m_Triangles};
+    rtbuild::BvhBuilder<MirrorTriView> bvh{view, m_Bvh, {}, {}, {}, {}};
+    bvh.Run();
+    static std::atomic<uint64_t> late{1ull << 62};
+    m_Revision = ++late;  // the flattened geometry changes: a renderer must not keep what it uploaded
+}
+
+Triangle &Mesh::AddTriangle() {
+    m_Triangles.emplace_back();
+    return m_Triangles.back();
+}
 
 void Mesh::Compile() {
     if (!m_Invalidated) return;
@@ -146,8 +164,15 @@ void Mesh::Compile() {
     rtbuild::KdBuilder<MirrorTriView> builder{view, m_KdTree};
     builder.Build(all, root, 0, BuildForkDepth());
     auto T1 = std::chrono::steady_clock::now();
-    rtbuild::BvhBuilder<MirrorTriView> bvh{view, m_Bvh, {}, {}, {}, {}};
-    bvh.Run();
+    // The 4-wide BVH of a big mesh is left to the device (rthip_upload_scene_ex + RTHIP_UPLOAD_BUILD_BVH: milliseconds instead
+    // of most of a second, and its leaf-order triangle copy is never made or uploaded); small meshes keep the host's
+    // binned-SAH build, which costs nothing at their size and walks a little faster.  RE_BVH_DEVICE_MIN_TRIS moves the limit
+    // (0 = always on the host).
+    m_Bvh = BvhFlat();
+    if (!BvhBuiltOnDevice()) {
+        rtbuild::BvhBuilder<MirrorTriView> bvh{view, m_Bvh, {}, {}, {}, {}};
+        bvh.Run();
+    }
     auto T2 = std::chrono::steady_clock::now();
     if (getenv("RE_BUILD_TIMING")) fprintf(stderr, "Mesh::Compile %zu tris: kd %.3f s, bvh %.3f s\n", m_Triangles.size(), std::chrono::duration<double>(T1 - T0).count(), std::chrono::duration<double>(T2 - T1).count());
     m_Invalidated = false;

@@ -1,0 +1,125 @@
+"""The 4-wide BVH built ON THE DEVICE (rthip_upload_scene_ex + RTHIP_UPLOAD_BUILD_BVH, raytracing_amd/csrc/rthip_bvh.hip;
+SURVEY.md §8f rank 3).  The BVH takes no part in a result's arithmetic, so frames must stay bit-identical to the goldens of the
+genuine reference whichever builder made it; the structure itself must be complete (every triangle in exactly one leaf) and
+conservative (every triangle inside all the outward-rounded fp32 boxes on its path)."""
+import numpy as np
+import pytest
+
+from conftest import FRAME_CASES, assert_frame_parity
+from raytracing_amd import device, host, scenes
+
+pytestmark = pytest.mark.gpu
+
+
+def _check_bvh(mesh, nodes, index, verts):
+    n_tris = len(index)
+    assert mesh.bvh_node_count == len(nodes) and mesh.tri_count == n_tris
+    assert np.array_equal(np.sort(index), np.arange(n_tris, dtype=np.uint32))   # a permutation: no triangle lost or duplicated
+    seen = np.zeros(n_tris, bool)
+    stack = [(0, np.full(3, -np.inf), np.full(3, np.inf), 0)]
+    visited, deepest = 0, 0
+    while stack:
+        ni, lo, hi, depth = stack.pop()
+        visited += 1
+        deepest = max(deepest, depth)
+        n_children = 0
+        for ch in nodes[ni]["c"]:
+            c, blo, bhi = int(ch["child"]), ch["lo"], ch["hi"]
+            if c == 0xffffffff:
+                continue
+            n_children += 1
+            clo, chi = np.maximum(lo, blo.astype(np.float64)), np.minimum(hi, bhi.astype(np.float64))
+            if c & 0x80000000:
+                first, cnt = c & 0x0fffffff, ((c >> 28) & 7) + 1
+                assert cnt <= 4 and first + cnt <= n_tris
+                t = index[first:first + cnt]
+                assert not seen[t].any()
+                seen[t] = True
+                assert (verts[t] >= clo).all() and (verts[t] <= chi).all(), "triangle sticks out of its boxes"
+            else:
+                assert ni < c < len(nodes)                                     # children follow their parent
+                stack.append((c, clo, chi, depth + 1))
+        assert n_children >= 1
+    assert visited == len(nodes) and seen.all()
+    assert deepest == mesh.bvh_depth <= 48
+    assert mesh.abs_max >= np.abs(verts).max()
+
+
+def test_device_built_bvh_of_the_bunny_is_complete_and_conservative(monkeypatch):
+    monkeypatch.setenv("RE_BVH_DEVICE_MIN_TRIS", "1")
+    hs = host.HostScene(scenes.config(3)[0])
+    ctx = device.Context(0)
+    try:
+        ctx.upload(hs.flatten())
+        m, nodes, index = ctx.bvh(0)
+        assert 400 < len(nodes) < 4968
+        _check_bvh(m, nodes, index, scenes.load_bunny()[0].reshape(-1, 3, 3))
+    finally:
+        ctx.close()
+
+
+def test_device_built_bvh_of_a_height_field_and_of_tiny_meshes():
+    v, _ = scenes.heightfield_mesh(384, seed=1234)      # 294 912 triangles: above the host library's 2^18 limit by default
+    hs = host.HostScene(scenes.config(4, cells=384)[0])
+    ctx = device.Context(0)
+    try:
+        ctx.upload(hs.flatten())
+        m, nodes, index = ctx.bvh(0)
+        _check_bvh(m, nodes, index, v.reshape(-1, 3, 3))
+    finally:
+        ctx.close()
+
+
+@pytest.mark.parametrize("n_tris", [1, 2, 4, 5, 9])
+def test_device_built_bvh_of_meshes_of_a_few_triangles(monkeypatch, oracle_lib, n_tris):
+    """(also the regression test of the quad walk's stack size: a BVH that is a lone root pushes up to three children at once;
+    the large overlapping triangles here make that happen, and 3 * depth + 1 entries lost hits in both builders' trees)"""
+    monkeypatch.setenv("RE_BVH_DEVICE_MIN_TRIS", "1")
+    rng = np.random.default_rng(n_tris)
+    v = rng.uniform(-2, 2, (n_tris, 9))
+    sd = scenes.SceneDesc("few triangles")
+    sd.camera((0, 0, 6))
+    sd.mesh(sd.uniform_material(0xffffff, 0.9), v, np.tile([0.0, 0, 1], (n_tris, 3)), scenes.NORMAL_FACE)
+    sd.ambient_light(0xffffff)
+    sd.color_background(0x102030)
+    hs = host.HostScene(sd)
+    ctx = device.Context(0)
+    try:
+        ctx.upload(hs.flatten())
+        m, nodes, index = ctx.bvh(0)
+        _check_bvh(m, nodes, index, v.reshape(-1, 3, 3))
+        got = ctx.render(hs.camera(96, 64), device.make_params(96, 64, 1), ids=True)
+    finally:
+        ctx.close()
+    monkeypatch.setenv("RE_BVH_DEVICE_MIN_TRIS", "0")
+    host_built = host.HostScene(sd).render(96, 64, max_recursion=1, ids=True)
+    want = sd.build(oracle_lib).render(96, 64, max_recursion=1, ids=True, threads=4)
+    assert (want["tri"] >= 0).sum() > 200
+    for k in ("pixels", "shape", "tri"):
+        assert np.array_equal(got[k], want[k]), f"device-built BVH: {k}"
+        assert np.array_equal(host_built[k], want[k]), f"host-built BVH: {k}"
+
+
+@pytest.mark.parametrize("name", ["cfg3", "cfg3close", "nested", "nested_ssaa"])
+def test_frames_with_device_built_bvhs_match_the_reference_golden(golden, monkeypatch, name):
+    """re::HipRaytracer end to end with EVERY mesh's BVH built on the device: the golden frames of the genuine reference"""
+    monkeypatch.setenv("RE_BVH_DEVICE_MIN_TRIS", "1")
+    mk, w, h, kw = FRAME_CASES[name]
+    got = host.HostScene(mk()).render(w, h, ids=True, **kw)
+    f = golden["frames"]
+    diff, ids_bad = assert_frame_parity(got, f[name + "_pixels"], f[name + "_shape"].astype(np.int32), f[name + "_tri"], name)
+    assert diff == 0 and ids_bad == 0 and got["rays"] == int(f[name + "_rays"][0])
+
+
+def test_host_and_device_built_bvhs_give_the_same_frame_and_geometry_is_kept(monkeypatch):
+    sd = scenes.config(5, cells=96)[0]     # five rotated / scaled meshes of 18 432 triangles + plane + spheres
+    monkeypatch.setenv("RE_BVH_DEVICE_MIN_TRIS", "0")
+    want = host.HostScene(sd).render(320, 180, max_recursion=4, ids=True)
+    monkeypatch.setenv("RE_BVH_DEVICE_MIN_TRIS", "1")
+    hs = host.HostScene(sd)
+    got = hs.render(320, 180, max_recursion=4, ids=True)
+    for k in ("pixels", "shape", "tri"):
+        assert np.array_equal(got[k], want[k]), k
+    assert got["rays"] == want["rays"]
+    second, kept = hs.render_moved(320, 180, 0.3, max_recursion=4)   # the next frame keeps the device geometry, device-built BVHs included
+    assert kept and np.array_equal(second, hs.render(320, 180, max_recursion=4)["pixels"])

@@ -175,11 +175,28 @@ def _flat_arrays(desc):
             "bvh_tri_index": raw(d.bvh_tri_index, 4 * d.n_tris)}, (d.n_tris, d.n_kd_nodes, d.n_bvh_nodes)
 
 
+def test_big_meshes_leave_their_bvh_to_the_device(host_lib, monkeypatch):
+    """at 2^18 triangles and above Mesh::Compile skips the host BVH: the flattened mesh has no BVH arrays and the upload is to
+    be made with RTHIP_UPLOAD_BUILD_BVH; the kd-tree (the reference's, parity-relevant) is still the host's"""
+    import ctypes as C
+    from raytracing_amd import device
+    sd = scenes.config(4, cells=384)[0]
+    d = C.cast(host.HostScene(sd).flatten(), C.POINTER(device.SceneDesc)).contents
+    assert d.n_tris == 294912 and d.n_bvh_nodes == 0 and d.meshes[0].bvh_node_count == 0 and d.meshes[0].node_count > 1000
+    monkeypatch.setenv("RE_BVH_DEVICE_MIN_TRIS", "0")
+    d = C.cast(host.HostScene(sd).flatten(), C.POINTER(device.SceneDesc)).contents
+    assert d.n_bvh_nodes > 10000 and d.meshes[0].bvh_node_count == d.n_bvh_nodes
+    monkeypatch.setenv("RE_BVH_DEVICE_MIN_TRIS", "1000")
+    d = C.cast(host.HostScene(scenes.config(3)[0]).flatten(), C.POINTER(device.SceneDesc)).contents
+    assert d.n_tris == 4968 and d.n_bvh_nodes == 0
+
+
 def test_threaded_scene_build_gives_the_single_threaded_arrays(host_lib, monkeypatch):
     """Mesh::Compile builds big sub-trees of the kd-tree and of the BVH on host threads (and bins the top BVH nodes in
     slices); every flattened array must be byte-identical to the single-threaded build (the kd-tree's splits are the
     reference's: sequential sums in triangle order per node)."""
     sd = scenes.config(4, cells=384)[0]   # 294 912 triangles: above the fork and the sliced-binning thresholds
+    monkeypatch.setenv("RE_BVH_DEVICE_MIN_TRIS", "0")   # the host BVH builder is what is tested (at this size the device would build it)
     out = {}
     for threads in ("1", "8", "3"):
         monkeypatch.setenv("RE_BUILD_THREADS", threads)
