@@ -94,7 +94,7 @@ def test_device_built_bvh_of_meshes_of_a_few_triangles(monkeypatch, oracle_lib, 
     monkeypatch.setenv("RE_BVH_DEVICE_MIN_TRIS", "0")
     host_built = host.HostScene(sd).render(96, 64, max_recursion=1, ids=True)
     want = sd.build(oracle_lib).render(96, 64, max_recursion=1, ids=True, threads=4)
-    assert (want["tri"] >= 0).sum() > 200
+    assert n_tris < 4 or (want["tri"] >= 0).sum() > 200   # (a lone random triangle may face away: back-face culled)
     for k in ("pixels", "shape", "tri"):
         assert np.array_equal(got[k], want[k]), f"device-built BVH: {k}"
         assert np.array_equal(host_built[k], want[k]), f"host-built BVH: {k}"

@@ -412,7 +412,7 @@ def test_scene_with_a_mesh_that_has_no_bvh_is_refused_by_the_bvh_path(ctx):
     meshes = (device.Mesh * 1)(device.Mesh.from_buffer_copy(full.meshes[0]))
     meshes[0].bvh_node_count = 0
     kd_only.meshes = meshes
-    ctx.upload(C.addressof(kd_only))
+    ctx.upload(C.addressof(kd_only), build_bvh=False)   # (with RTHIP_UPLOAD_BUILD_BVH the device would build the missing BVH)
     cam = hs.camera(96, 54)
     with pytest.raises(device.RthipError) as e:
         ctx.render(cam, device.make_params(96, 54, 2))
