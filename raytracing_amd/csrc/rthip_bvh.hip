@@ -186,35 +186,41 @@ __global__ __launch_bounds__(kB) void k_ploc_init(const Box *prim_box, const uin
     cref[i] = 0x80000000u | i;
     csize[i] = 1u;
 }
-__global__ __launch_bounds__(kB) void k_ploc_nn(const Box *cbox, uint32_t n, uint32_t *nn, int kRadius) {
+// max_size > 0: only unions of at most max_size triangles are considered (the leaf-forming passes)
+__global__ __launch_bounds__(kB) void k_ploc_nn(const Box *cbox, const uint32_t *csize, uint32_t n, uint32_t *nn, int kRadius, uint32_t max_size) {
     __shared__ Box sh[kB + 2 * kRadiusMax];
+    __shared__ uint32_t shs[kB + 2 * kRadiusMax];
     const int base = (int)(blockIdx.x * kB) - kRadius;
     for (int k = threadIdx.x; k < (int)kB + 2 * kRadius; k += kB) {
         const int j = base + k;
-        if (j >= 0 && j < (int)n) sh[k] = cbox[j];
+        if (j >= 0 && j < (int)n) {
+            sh[k] = cbox[j];
+            shs[k] = csize[j];
+        }
     }
     __syncthreads();
     const int i = (int)(blockIdx.x * kB + threadIdx.x);
     if (i >= (int)n) return;
     const Box me = sh[threadIdx.x + kRadius];
+    const uint32_t room = max_size ? max_size - min(max_size, shs[threadIdx.x + kRadius]) : 0xffffffffu;  // triangles a partner may bring
     // Ties go to the partner i ^ 1, then to the lower position: equal boxes (duplicated triangles) then pair up two by two
     // instead of forming one chain of one-sided choices that merges a single pair per pass.
     float best = FLT_MAX;
     int who = -1;
     {
         const int j = i ^ 1;
-        if (j < (int)n) {
+        if (j < (int)n && shs[threadIdx.x + kRadius + (j - i)] <= room) {
             best = area(merge(me, sh[threadIdx.x + kRadius + (j - i)]));
             who = j;
         }
     }
     for (int d = -kRadius; d <= kRadius; d++) {
         const int j = i + d;
-        if (d == 0 || j < 0 || j >= (int)n) continue;
+        if (d == 0 || j < 0 || j >= (int)n || shs[threadIdx.x + kRadius + d] > room) continue;
         const float a = area(merge(me, sh[threadIdx.x + kRadius + d]));
         if (a < best) { best = a; who = j; }
     }
-    nn[i] = (uint32_t)who;
+    nn[i] = (uint32_t)who;  // 0xffffffff: nobody
 }
 __global__ __launch_bounds__(kB) void k_ploc_merge(const uint32_t *nn, const Box *cbox, const uint32_t *cref, const uint32_t *csize, uint32_t n, PNode *nodes,
                                                    Box *node_box, uint32_t *node_count, uint32_t *valid, Box *obox, uint32_t *oref, uint32_t *osize) {
@@ -465,13 +471,16 @@ static int build_nodes(hipStream_t stream, const rthip_tri *d_tris, uint32_t n, 
     uint32_t nc = n;
     int radius = 16;
     if (const char *e = getenv("RTHIP_PLOC_RADIUS")) radius = atoi(e) < 1 ? 1 : (atoi(e) > kRadiusMax ? kRadiusMax : atoi(e));
+    // (Passes that first form leaves of at most four triangles - leaf_limit = 4 - fill the leaves better, 3.6 instead of 3.1
+    // triangles, but the greedy groups have worse boxes: 4 % more traversal steps and 8 % slower frames on config 4.  Off.)
+    uint32_t leaf_limit = 0;
     for (int pass = 0; nc > 1; pass++) {
         if (pass > 4096) {
             snprintf(err, err_len, "BVH build: clustering did not converge (%u clusters left)", nc);
             return RTHIP_E_UNSUPPORTED;  // (the caller may build this BVH on the host instead)
         }
         const uint32_t g = (nc + kB - 1) / kB;
-        hipLaunchKernelGGL(k_ploc_nn, dim3(g), dim3(kB), 0, stream, boxA.as<Box>(), nc, nn.as<uint32_t>(), radius);
+        hipLaunchKernelGGL(k_ploc_nn, dim3(g), dim3(kB), 0, stream, boxA.as<Box>(), sizeA.as<uint32_t>(), nc, nn.as<uint32_t>(), radius, leaf_limit);
         hipLaunchKernelGGL(k_ploc_merge, dim3(g), dim3(kB), 0, stream, nn.as<uint32_t>(), boxA.as<Box>(), refA.as<uint32_t>(), sizeA.as<uint32_t>(), nc, bin.as<PNode>(),
                            node_box.as<Box>(), cnt + 4, valid.as<uint32_t>(), boxB.as<Box>(), refB.as<uint32_t>(), sizeB.as<uint32_t>());
         BHIP(rocprim::exclusive_scan(scan_tmp.p, scan_bytes, valid.as<uint32_t>(), pos.as<uint32_t>(), 0u, (size_t)nc, rocprim::plus<uint32_t>(), stream));
@@ -480,7 +489,11 @@ static int build_nodes(hipStream_t stream, const rthip_tri *d_tris, uint32_t n, 
         uint32_t left = 0;
         BHIP(hipMemcpyAsync(&left, cnt + 5, sizeof left, hipMemcpyDeviceToHost, stream));
         BHIP(hipStreamSynchronize(stream));
-        if (left == 0 || left >= nc) {  // (every pass merges at least the globally closest pair)
+        if (leaf_limit && left == nc) {  // no pair of at most four triangles left: on to the tree above the leaves
+            leaf_limit = 0;
+            continue;
+        }
+        if (left == 0 || left >= nc) {  // (every unrestricted pass merges at least the globally closest pair)
             snprintf(err, err_len, "BVH build: clustering pass %d went from %u to %u clusters", pass, nc, left);
             return RTHIP_E_HIP;
         }
