@@ -10,7 +10,7 @@ HBM, the buffers are gathered to rank 0 over RCCL (--collective all_gather: to e
 the frames on the device; total work
 is fixed as N grows ("strong" scaling).
 
-Frames are traced in runs: one rthip_render_batch_device call takes --batch frames (default 8 on one GPU, 16 on several; the same camera for
+Frames are traced in runs: one rthip_render_batch_device call takes --batch frames (default 8 per GPU: 8, 16, 32, 64 on 1, 2, 4, 8 GPUs; the same camera for
 all of them here, but every frame is traced in full — nothing is reused between frames) through ONE set of kernel
 launches, and --inflight calls (default 3) are in flight on separate HIP streams.  A run of frames is what a camera
 path rendered ahead of time looks like; it is also what keeps a GPU busy when its share of a 1080p frame is an
@@ -203,7 +203,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--inflight", type=int, default=0, help="calls in flight (one context + HIP stream each); 0 = 3")
     ap.add_argument("--batch", type=int, default=0, help="frames traced per call (rthip_render_batch_device: one set of launches for "
-                    "the rays of all of them); 0 = 8 on one GPU, 16 (the library's limit) on several")
+                    "the rays of all of them); 0 = 8 per GPU (8, 16, 32, 64 on 1, 2, 4, 8 GPUs; the library's limit is 64)")
     ap.add_argument("--latency", action="store_true", help="(kept for old command lines: lone-frame latency is measured by default now)")
     ap.add_argument("--no-extras", action="store_true", help="skip what runs AFTER the timed region besides the roofline launches: the lone-frame "
                     "latency, the D2H-inclusive frames and the config-4 frames.  For `rocprofv3 --kernel-trace --stats -- python3 bench.py "
@@ -256,9 +256,10 @@ def main():
     prm = device.make_params(W, H, MAX_REC, part_index=rank, part_count=world, layout=1 if gather else 0)
 
     part_px = device.part_pixels(prm)
-    # 8 frames per call on one GPU (8 x 2.07 M primary rays = one workspace chunk); a rank's share of a frame shrinks
-    # with the rank count, so several GPUs take the library's limit of 16
-    B = args.batch if args.batch > 0 else (8 if world == 1 else device.MAX_BATCH)
+    # 8 frames per call on one GPU (8 x 2.07 M primary rays = one workspace chunk); a rank's share of a frame shrinks with the
+    # rank count, so N GPUs take 8 N frames per call (the library's limit is 64): every rank's launches then carry the rays of
+    # 8 whole frames whatever N is
+    B = args.batch if args.batch > 0 else min(device.MAX_BATCH, 8 * world)
     if B > device.MAX_BATCH:
         raise SystemExit(f"--batch {B} > {device.MAX_BATCH}")
     cam_runs = {n: (device.Camera * n)(*([cam] * n)) for n in range(1, B + 1)}

@@ -113,7 +113,7 @@ typedef struct {
 #define RTHIP_BVH_COUNT_SHIFT 28
 #define RTHIP_BVH_FIRST_MASK 0x0fffffffu
 #define RTHIP_BVH_MAX_LEAF 4
-#define RTHIP_MAX_BATCH 16 /* frames per rthip_render_batch_device call (their cameras travel as kernel arguments) */
+#define RTHIP_MAX_BATCH 64 /* frames per rthip_render_batch_device call */
 #define RTHIP_BVH_MAX_DEPTH 48
 
 typedef struct {

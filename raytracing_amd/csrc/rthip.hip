@@ -106,7 +106,8 @@ enum { ST_KD_NODES = 0, ST_KD_TRIS, ST_KD_LEAVES, ST_KD_POPS, ST_SHAPES, ST_MESH
 
 // Per-frame constants
 struct FrameParams {
-    rthip_camera cams[RTHIP_MAX_BATCH];  // one per frame of the batch (a plain frame is a batch of one)
+    const rthip_camera *cams;  // device: one per frame of the batch (a plain frame is a batch of one); written by k_clear at the
+                               // head of the call's launches (kernel arguments hold 16 cameras, a batch up to RTHIP_MAX_BATCH)
     uint32_t n_frames;
     uint32_t my_tiles;     // tiles of this part in ONE frame: per-part tile ordinal q = frame * my_tiles + tile
     uint32_t part_slots;   // pixel slots of one frame's tile-compact part buffer (rthip_part_pixels)
@@ -166,14 +167,23 @@ struct Work {
     uint32_t bs_stride;
     uint32_t N;
     // Interrupt() / RenderStatus::Percent at kernel granularity (Raytracer.cpp:91-99, 150-154): `irq` is a word in FINE-GRAINED
-    // device memory (not cached in L2, so a write made while a kernel runs is seen by that kernel) that rthip_interrupt sets
-    // through a side stream; every workgroup reads it when it starts and once per grid-stride iteration and leaves when it is
+    // device memory (not cached in L2, so a write made while a kernel runs is seen by that kernel) raised by the watcher
+    // workgroup (irq_load); every workgroup reads it when it starts and once per grid-stride iteration and leaves when it is
     // set.  `stage` is a word in page-locked host memory: workgroup 0 of every kernel stores the index of the stage it begins.
     const uint32_t *irq;
+    const uint32_t *irq_host;   // the request itself: a word in page-locked host memory that rthip_interrupt stores to
     uint32_t *stage;
     uint32_t stage_base;        // stage index of the current chunk's first kernel
 };
-__device__ __forceinline__ uint32_t irq_load(const Work &w) { return __hip_atomic_load(w.irq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+// Workgroup 0 of every kernel is the watcher: it reads the request word in host memory (a PCIe read, so only this one workgroup
+// does it, once per grid-stride iteration - its iterations are spread over the kernel's whole run) and raises the device-side
+// flag; everybody polls that flag, which costs an uncached read of HBM.  (Raising the device flag from the host with
+// hipMemsetAsync / hipMemcpyAsync on a side stream waited for a free slot on a saturated GPU: 20 ms.)
+__device__ __forceinline__ uint32_t irq_load(const Work &w) {
+    if (blockIdx.x == 0 && __hip_atomic_load(w.irq_host, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM))
+        __hip_atomic_store(const_cast<uint32_t *>(w.irq), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    return __hip_atomic_load(w.irq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 __device__ __forceinline__ uint32_t irq_load_wave(const Work &w) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)irq_load(w)); }
 __device__ __forceinline__ void stage_store(const Work &w, uint32_t stage) {
     if (blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(w.stage, stage, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -245,7 +255,10 @@ __device__ __forceinline__ bool primary_ray(const FrameParams &fp, uint32_t i, b
     }
     frame = (uint32_t)__builtin_amdgcn_readfirstlane((int)frame);
     if (frame >= fp.n_frames) frame = 0;
-    screen_ray(fp.cams[frame], fp.W, fp.H, fx, fy, o, d);
+    typedef const __attribute__((address_space(4))) rthip_camera uniform_camera;  // wave-uniform index: scalar loads
+    rthip_camera cam;
+    __builtin_memcpy(&cam, (uniform_camera *)(fp.cams + frame), sizeof cam);
+    screen_ray(cam, fp.W, fp.H, fx, fy, o, d);
     return live && inside;
 }
 
@@ -1130,6 +1143,16 @@ __global__ __launch_bounds__(kBlock) void k_clear(uint32_t *a, uint32_t na, uint
     if (i < nb) b[i] = 0u;
     if (i < nc) c[i] = 0u;
 }
+// the cameras of a call, 16 per launch (kernel arguments), into the context's device camera array
+static const uint32_t kCamsPerLaunch = 16;
+struct CamPack {
+    rthip_camera c[kCamsPerLaunch];
+};
+__global__ __launch_bounds__(kBlock) void k_set_cams(rthip_camera *dst, uint32_t count, CamPack pack) {
+    const uint32_t words = count * (uint32_t)(sizeof(rthip_camera) / 4);
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(&pack);
+    for (uint32_t k = threadIdx.x; k < words; k += kBlock) reinterpret_cast<uint32_t *>(dst)[k] = src[k];
+}
 __global__ __launch_bounds__(kBlock) void k_fill(uint32_t *a, size_t n, uint32_t value) {
     for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) a[i] = value;
 }
@@ -1264,13 +1287,13 @@ struct rthip_ctx {
     int mesh_without_bvh = -1;  // first mesh that has triangles but no BVH (a caller that supplied only the kd-tree), -1 = none
     std::atomic<int> interrupt{0};
     std::atomic<float> progress{0.f};
-    // device-visible side of Interrupt() / Percent (see Work::irq): the flag the kernels poll, its side stream, and the stage
-    // word the kernels store to (page-locked host memory)
+    // device-visible side of Interrupt() / Percent (see Work::irq): the flag the kernels poll, and in page-locked host memory
+    // the stage word the kernels store to (h_stage[0]) and the request word rthip_interrupt stores to (h_stage[32])
+    rthip_camera *d_cams = nullptr;    // RTHIP_MAX_BATCH cameras of the call in flight (all calls of a context run on one stream, in order)
     uint32_t *d_irq = nullptr;
     bool irq_finegrained = false;
     bool irq_dirty = false;            // d_irq may be non-zero (guarded by irq_mutex)
     std::mutex irq_mutex;
-    hipStream_t side = nullptr;
     volatile uint32_t *h_stage = nullptr;
     std::atomic<uint32_t> stages_total{0};
     rthip_stats last{};
@@ -1327,7 +1350,6 @@ int rthip_create(int device, rthip_ctx **out) {
         }
     }
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking);
     if (e == hipSuccess) {  // fine-grained device memory is not cached in L2: a running kernel sees the write of rthip_interrupt
         if (hipExtMallocWithFlags((void **)&c->d_irq, 256, hipDeviceMallocFinegrained) == hipSuccess && c->d_irq) {
             c->irq_finegrained = true;
@@ -1338,8 +1360,9 @@ int rthip_create(int device, rthip_ctx **out) {
         }
     }
     if (e == hipSuccess) e = hipMemset(c->d_irq, 0, 256);
+    if (e == hipSuccess) e = hipMalloc((void **)&c->d_cams, sizeof(rthip_camera) * RTHIP_MAX_BATCH);
     if (e == hipSuccess) e = hipHostMalloc((void **)&c->h_stage, 256, hipHostMallocMapped);
-    if (e == hipSuccess) c->h_stage[0] = 0;
+    if (e == hipSuccess) c->h_stage[0] = c->h_stage[32] = 0;
     if (e == hipSuccess) e = hipEventCreate(&c->ev0);
     if (e == hipSuccess) e = hipEventCreate(&c->ev1);
     if (e != hipSuccess) {
@@ -1371,8 +1394,8 @@ int rthip_destroy(rthip_ctx *c) {
     for (auto &g : c->graphs) (void)hipGraphExecDestroy(g.exec);
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->d_irq) (void)hipFree(c->d_irq);
+    if (c->d_cams) (void)hipFree(c->d_cams);
     if (c->h_stage) (void)hipHostFree((void *)c->h_stage);
-    if (c->side) (void)hipStreamDestroy(c->side);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -1399,10 +1422,10 @@ int rthip_interrupt(rthip_ctx *c) {
     if (!c) return fail(RTHIP_E_INVALID, "null context");
     std::lock_guard<std::mutex> lock(c->irq_mutex);
     c->interrupt.store(1);
-    // tell the kernels that are running or queued: the flag goes to the device on a stream of its own
-    if (c->d_irq && hipSetDevice(c->device) == hipSuccess) {
+    // tell the kernels that are running or queued: a store to the page-locked word their watcher workgroup reads
+    if (c->h_stage) {
         c->irq_dirty = true;
-        if (hipMemsetAsync(c->d_irq, 0xff, sizeof(uint32_t), c->side) == hipSuccess) (void)hipStreamSynchronize(c->side);
+        __atomic_store_n(const_cast<uint32_t *>(c->h_stage + 32), 1u, __ATOMIC_RELEASE);
     }
     return 0;
 }
@@ -1733,6 +1756,7 @@ static int render_frame(rthip_ctx *c, const rthip_camera *cam, uint32_t n_frames
         std::lock_guard<std::mutex> lock(c->irq_mutex);
         if (c->irq_dirty) {  // the flag of an earlier frame is still up: let that frame's kernels drain, then lower it
             HIP_TRY(hipStreamSynchronize(c->stream));
+            c->h_stage[32] = 0;
             HIP_TRY(hipMemset(c->d_irq, 0, sizeof(uint32_t)));
             c->irq_dirty = false;
         }
@@ -1744,7 +1768,7 @@ static int render_frame(rthip_ctx *c, const rthip_camera *cam, uint32_t n_frames
 
     FrameParams fp;
     memset(&fp, 0, sizeof fp);
-    for (uint32_t b = 0; b < n_frames; b++) fp.cams[b] = cam[b];
+    fp.cams = c->d_cams;
     fp.n_frames = n_frames;
     fp.part_slots = (uint32_t)rthip_part_pixels(p);
     fp.W = p->width;
@@ -1830,6 +1854,7 @@ static int render_frame(rthip_ctx *c, const rthip_camera *cam, uint32_t n_frames
     w.bs_stride = bs_stride;
     w.N = (uint32_t)N;
     w.irq = c->d_irq;
+    w.irq_host = (const uint32_t *)(c->h_stage + 32);
     w.stage = (uint32_t *)c->h_stage;
     w.stage_base = 0;
     const uint32_t stages_per_chunk = STAGES_PER_LEVEL * levels + 1;  // + k_resolve
@@ -1886,6 +1911,13 @@ static int render_frame(rthip_ctx *c, const rthip_camera *cam, uint32_t n_frames
     uint64_t pixels_done = 0;
     bool interrupted = false;
     auto enqueue = [&]() -> int {
+    for (uint32_t b0 = 0; b0 < n_frames; b0 += kCamsPerLaunch) {  // the call's cameras -> device (a kernel: ordered like the rest)
+        CamPack pack;
+        const uint32_t cnt = n_frames - b0 < kCamsPerLaunch ? n_frames - b0 : kCamsPerLaunch;
+        memcpy(pack.c, cam + b0, sizeof(rthip_camera) * cnt);
+        if (cnt < kCamsPerLaunch) memset(pack.c + cnt, 0, sizeof(rthip_camera) * (kCamsPerLaunch - cnt));
+        hipLaunchKernelGGL(k_set_cams, dim3(1), dim3(kBlock), 0, c->stream, c->d_cams + b0, cnt, pack);
+    }
     {
         const uint32_t na = 2 * ST_COUNT, nb = (uint32_t)(2 * 2 * (size_t)bs_stride * levels);
         const uint32_t most = na > nb ? na : nb;

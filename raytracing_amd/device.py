@@ -22,7 +22,7 @@ SYMBOLS = ["rthip_create", "rthip_destroy", "rthip_last_error", "rthip_upload_sc
            "rthip_host_free", "rthip_update_scene", "rthip_render_device_noalloc", "rthip_collect_stats", "rthip_multi_create",
            "rthip_multi_destroy", "rthip_multi_device_count", "rthip_multi_context", "rthip_multi_transport", "rthip_multi_upload_scene",
            "rthip_multi_render", "rthip_multi_progress", "rthip_multi_interrupt", "rthip_upload_scene_ex", "rthip_probe_bvh"]
-MAX_BATCH = 16  # RTHIP_MAX_BATCH
+MAX_BATCH = 64  # RTHIP_MAX_BATCH
 UPLOAD_BUILD_BVH, UPLOAD_KEEP_GEOMETRY = 1, 2  # RTHIP_UPLOAD_*
 
 

@@ -96,4 +96,4 @@ def test_bench_multi_rank_control_flow_on_one_gpu():
     assert d["n_gpus"] == 2 and d["steps"] == 32 and "rehearsal" in d
     assert d["config"]["rays_per_frame"] == ref["config"]["rays_per_frame"] == 4589295      # the two parts' rays add up
     assert d["config"]["frame_checksum"] == ref["config"]["frame_checksum"]                # gathered + assembled = the 1-GPU frame
-    assert d["config"]["frames_per_call"] == 16 and "cpu_baseline" not in d
+    assert d["config"]["frames_per_call"] == 16 and "cpu_baseline" not in d   # 8 frames per call and rank

@@ -327,7 +327,30 @@ def test_frame_batches_are_bit_identical_to_single_frames(ctx):
         for k in range(3):
             assert np.array_equal(got[k], singles[k]), f"{parts} parts frame {k}"
     with pytest.raises(device.RthipError):
-        ctx.render_batch_device(cams * 4, prm, buf.data_ptr(), sync=True)  # 20 > RTHIP_MAX_BATCH
+        ctx.render_batch_device(cams * 13, prm, buf.data_ptr(), sync=True)  # 65 > RTHIP_MAX_BATCH
+
+
+def test_batch_of_forty_cameras_equals_forty_single_frames(ctx):
+    """more cameras than one launch's kernel arguments hold (16): they reach the device through the context's camera array"""
+    import torch
+    hs = host.HostScene(scenes.config(3, cam_z=2.6)[0])
+    ctx.upload(hs.flatten())
+    w, h, n = 96, 56, 40
+    prm = device.make_params(w, h, 2)
+    cams = []
+    for k in range(n):
+        cam = hs.camera(w, h)
+        cam.position[0] += 0.04 * k - 0.8
+        cam.position[1] += 0.01 * (k % 7)
+        cams.append(cam)
+    buf = torch.zeros(n * w * h, dtype=torch.int32, device="cuda")
+    ctx.render_batch_device(cams, prm, buf.data_ptr(), sync=True)
+    got = buf.cpu().numpy().view(np.uint32).reshape(n, h, w)
+    one = torch.zeros(w * h, dtype=torch.int32, device="cuda")
+    for k in (0, 1, 15, 16, 17, 31, 32, 39):
+        ctx.render_device(cams[k], prm, one.data_ptr(), sync=True)
+        assert np.array_equal(got[k], one.cpu().numpy().view(np.uint32).reshape(h, w)), f"frame {k}"
+    assert len({got[k].tobytes() for k in range(n)}) == n
 
 
 def test_chunked_frame_batch(monkeypatch):

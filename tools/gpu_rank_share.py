@@ -11,12 +11,12 @@ W, H, MR = 1920, 1080, 3
 sd, _ = scenes.config(3)
 hs = host.HostScene(sd); desc = hs.flatten(); cam = hs.camera(W, H)
 Fs = [int(f) for f in os.environ.get("RANKSHARE_F", "1,2,3").split(",")]
-Bs = [int(f) for f in os.environ.get("RANKSHARE_B", "1,2,4,8").split(",")]
+Bs = [int(f) for f in os.environ.get("RANKSHARE_B", "1,2,4,8").split(",")]  # 0 = 8 per part (the bench's default)
 K = int(os.environ.get("RANKSHARE_K", "480"))
 for N in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]:
     prm = device.make_params(W, H, MR, part_index=0, part_count=N, layout=1)
     px = device.part_pixels(prm)
-    for B in Bs:
+    for B in [b if b > 0 else min(64, 8 * N) for b in Bs]:
         cams = (device.Camera * B)(*([cam] * B))
         for F in Fs:
             ctxs = [device.Context(0) for _ in range(F)]
