@@ -188,6 +188,7 @@ __device__ __forceinline__ uint32_t irq_load_wave(const Work &w) { return (uint3
 __device__ __forceinline__ void stage_store(const Work &w, uint32_t stage) {
     if (blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(w.stage, stage, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
+static const uint32_t kIrqEvery = 8;  // grid-stride iterations between two polls of the interrupt flag (a power of two)
 enum { STAGE_EASY = 0, STAGE_WALK = 1, STAGE_SHADE = 2, STAGES_PER_LEVEL = 3 };
 
 __device__ __forceinline__ uint32_t &level_count(const Work &w, uint32_t level) { return w.counts[(size_t)level * kCounterStride]; }
@@ -329,10 +330,12 @@ __global__ __launch_bounds__(kBlock, RT_TRACE_OCC) void k_trace(SceneView sv, Fr
     uint32_t max_ray_nodes = 0;
     const long long t_start = COUNT ? clock64() : 0;
     if (!REDO) stage_store(w, w.stage_base + STAGES_PER_LEVEL * level + STAGE_WALK);
-    uint32_t irq = irq_load(w);
+    // Interrupt(): polled when the level's first kernel starts and then every kIrqEvery-th grid-stride iteration (an uncached
+    // read; vector loads return in order, so polling every iteration delayed each iteration's first fetch: 2.6 % on the bench)
+    if (!REDO && __builtin_amdgcn_readfirstlane((int)irq_load(w))) return;
+    uint32_t it = 0;
     for (uint32_t base = blockIdx.x * kBlock; base < n; base += gridDim.x * kBlock) {
-        if (__builtin_amdgcn_readfirstlane((int)irq)) break;  // wave-uniform (one address, one load)
-        irq = irq_load(w);  // read again for the next iteration: its latency hides behind this one
+        if ((++it & (kIrqEvery - 1u)) == 0u && __builtin_amdgcn_readfirstlane((int)irq_load(w))) break;  // wave-uniform
         const uint32_t j = base + threadIdx.x;
         const bool in_range = j < n;
         const uint32_t i = in_range ? (REDO ? w.redo[j] : j) : 0u;
@@ -951,7 +954,8 @@ __global__ __launch_bounds__(kBlock, RT_EASY_OCC) void k_trace_easy(SceneView sv
     stage_store(w, w.stage_base + STAGES_PER_LEVEL * level + STAGE_EASY);
     if (blockIdx.x * kBlock >= n) return;
     const uint8_t *tabs = reinterpret_cast<const uint8_t *>(lds_dyn);
-    uint32_t irq = threadIdx.x == 0 ? irq_load(w) : 0u;  // (in flight while the tables are staged)
+    const uint32_t irq = threadIdx.x == 0 ? irq_load(w) : 0u;  // (in flight while the tables are staged)
+    uint32_t it = 0;
     stage_perlin_tables(sv, n_tables);
     const uint32_t n_shadow = fp.renderer == RTHIP_RENDER_RAYTRACER ? sv.n_lights : 0u;  // DebugRaycaster: closest hit only
     const uint32_t lane = threadIdx.x & 63u;
@@ -959,12 +963,13 @@ __global__ __launch_bounds__(kBlock, RT_EASY_OCC) void k_trace_easy(SceneView sv
     uint32_t shadow_total = 0, spawn_total = 0;
     const long long t_start = COUNT ? clock64() : 0;
     for (uint32_t base = blockIdx.x * kBlock; base < n; base += gridDim.x * kBlock) {
-        // Interrupt(): thread 0 publishes what it read during the previous iteration (the barrier that ends shade_and_spawn
-        // orders the LDS word's reuse), the workgroup leaves together, and the flag is read again for the next iteration
-        if (threadIdx.x == 0) sh.irq = irq;
-        __syncthreads();
-        if (sh.irq) break;
-        if (threadIdx.x == 0) irq = irq_load(w);
+        // Interrupt(): thread 0 reads the flag (when the kernel starts, then every kIrqEvery-th iteration) and publishes it; the
+        // workgroup leaves together (its iterations contain barriers)
+        if ((it++ & (kIrqEvery - 1u)) == 0u) {
+            if (threadIdx.x == 0) sh.irq = it == 1u ? irq : irq_load(w);
+            __syncthreads();
+            if (sh.irq) break;
+        }
         const uint32_t j = base + threadIdx.x;
         bool live = j < n;
         const uint32_t i = live ? j : 0u;
@@ -1011,10 +1016,9 @@ __global__ __launch_bounds__(kBlock, RT_QUAD_OCC) void k_trace_quad(SceneView sv
     uint32_t max_ray_nodes = 0;
     const long long t_start = COUNT ? clock64() : 0;
     stage_store(w, w.stage_base + STAGES_PER_LEVEL * level + STAGE_WALK);
-    uint32_t irq = irq_load(w);
+    uint32_t it = 0;
     for (uint32_t base = blockIdx.x * quad::kRaysPerBlock; base < n; base += gridDim.x * quad::kRaysPerBlock) {
-        if (__builtin_amdgcn_readfirstlane((int)irq)) break;  // Interrupt(): wave-uniform, see Work::irq
-        irq = irq_load(w);
+        if ((++it & (kIrqEvery - 1u)) == 0u && __builtin_amdgcn_readfirstlane((int)irq_load(w))) break;  // Interrupt(): see k_trace
         const uint32_t j = base + g;
         bool live = j < n;
         const uint32_t i = live ? w.hard[j] : 0u;
@@ -1072,14 +1076,15 @@ __global__ __launch_bounds__(kBlock, RT_SHADE_OCC) void k_shade(SceneView sv, Fr
     stage_store(w, w.stage_base + STAGES_PER_LEVEL * level + STAGE_SHADE);
     if (blockIdx.x * kBlock >= n) return;
     const uint8_t *tabs = reinterpret_cast<const uint8_t *>(lds_dyn);
-    uint32_t irq = threadIdx.x == 0 ? irq_load(w) : 0u;
     stage_perlin_tables(sv, n_tables);
     uint32_t shadow_total = 0, spawn_total = 0;
+    uint32_t it = 0;
     for (uint32_t base = blockIdx.x * kBlock; base < n; base += gridDim.x * kBlock) {
-        if (threadIdx.x == 0) sh.irq = irq;  // Interrupt(): see k_trace_easy
-        __syncthreads();
-        if (sh.irq) break;
-        if (threadIdx.x == 0) irq = irq_load(w);
+        if ((++it & (kIrqEvery - 1u)) == 0u) {  // Interrupt(): see k_trace_easy (the level's first kernel polled at its start)
+            if (threadIdx.x == 0) sh.irq = irq_load(w);
+            __syncthreads();
+            if (sh.irq) break;
+        }
         const uint32_t j = base + threadIdx.x;
         uint32_t i = 0;
         HitSlot hs;
