@@ -129,37 +129,52 @@ def cpu_baseline(sd, frames=3):
 
 def config4_line(local_rank, frames=5):
     """BASELINE configs[3] on ONE GPU, lone frames left in HBM: the 2 097 152-triangle height field + 16 reflective spheres,
-    3840x2160, MaxRecursion 4 - the workload whose BVH + triangles (0.6 GB) do not fit L2, i.e. where HBM is the roof."""
+    3840x2160, MaxRecursion 4 - the workload whose BVH + triangles (0.6 GB) do not fit L2, i.e. where HBM is the roof.
+    Measured twice: with the BVH the host library builds (binned SAH on host threads: the better tree, value / ms_per_frame) and
+    with the one the device builds at upload (RTHIP_UPLOAD_BUILD_BVH, the library's default for meshes of 2^18 triangles and
+    more: start-up in a fraction of the time, frames ~20 % slower)."""
     import torch
     from raytracing_amd import device, host, scenes
-    t0 = time.perf_counter()
     sd, kw = scenes.config(4)
-    hs = host.HostScene(sd, device_index=local_rank)
-    desc = hs.flatten()
-    t1 = time.perf_counter()
     w, h, mr = kw["width"], kw["height"], kw["max_recursion"]
-    ctx = device.Context(local_rank)
-    ctx.upload(desc)
-    ctx.synchronize()
-    t2 = time.perf_counter()
-    cam, prm = hs.camera(w, h), device.make_params(w, h, mr)
-    fb = torch.zeros(w * h, dtype=torch.int32, device="cuda")
-    for _ in range(3):
-        ctx.render_device(cam, prm, fb.data_ptr(), sync=True)
-    st = ctx.stats()
-    rays = st.rays_primary + st.rays_shadow + st.rays_reflect
-    ts = []
-    for _ in range(frames):
-        t = time.perf_counter()
-        ctx.render_device(cam, prm, fb.data_ptr(), sync=True)
-        ts.append((time.perf_counter() - t) * 1e3)
-    ts.sort()
-    ms = ts[len(ts) // 2]
-    checksum = int(fb.to(torch.int64).sum().item())
-    ctx.close()
+    runs = {}
+    saved = os.environ.get("RE_BVH_DEVICE_MIN_TRIS")
+    for name, env in (("bvh_built_on_device", "1"), ("bvh_built_on_host", "0")):
+        os.environ["RE_BVH_DEVICE_MIN_TRIS"] = env
+        t0 = time.perf_counter()
+        hs = host.HostScene(sd, device_index=local_rank)
+        desc = hs.flatten()
+        t1 = time.perf_counter()
+        ctx = device.Context(local_rank)
+        ctx.upload(desc)
+        ctx.synchronize()
+        t2 = time.perf_counter()
+        cam, prm = hs.camera(w, h), device.make_params(w, h, mr)
+        fb = torch.zeros(w * h, dtype=torch.int32, device="cuda")
+        for _ in range(3):
+            ctx.render_device(cam, prm, fb.data_ptr(), sync=True)
+        st = ctx.stats()
+        rays = st.rays_primary + st.rays_shadow + st.rays_reflect
+        ts = []
+        for _ in range(frames):
+            t = time.perf_counter()
+            ctx.render_device(cam, prm, fb.data_ptr(), sync=True)
+            ts.append((time.perf_counter() - t) * 1e3)
+        ts.sort()
+        ms = ts[len(ts) // 2]
+        runs[name] = {"rays_per_frame": int(rays), "ms_per_frame": ms, "value": rays / ms / 1e3, "frame_checksum": int(fb.to(torch.int64).sum().item()),
+                      "scene_compile_flatten_s": t1 - t0, "scene_upload_and_device_build_s": t2 - t1}
+        ctx.close()
+        del hs
+    if saved is None:
+        os.environ.pop("RE_BVH_DEVICE_MIN_TRIS", None)
+    else:
+        os.environ["RE_BVH_DEVICE_MIN_TRIS"] = saved
+    best = runs["bvh_built_on_host"]
     out = {"workload": "BASELINE configs[3]: 2 097 152-triangle height field + 16 reflective spheres + SkyBox, 3840x2160, MaxRecursion 4, lone frames",
-           "rays_per_frame": int(rays), "ms_per_frame": ms, "value": rays / ms / 1e3, "unit": "Mrays/s", "frames": frames,
-           "frame_checksum": checksum, "scene_build_s": t1 - t0, "scene_upload_s": t2 - t1}
+           "rays_per_frame": best["rays_per_frame"], "ms_per_frame": best["ms_per_frame"], "value": best["value"], "unit": "Mrays/s", "frames": frames,
+           "frame_checksum": best["frame_checksum"], "frames_identical": runs["bvh_built_on_device"]["frame_checksum"] == best["frame_checksum"],
+           "bvh_built_on_host": runs["bvh_built_on_host"], "bvh_built_on_device": runs["bvh_built_on_device"]}
     pmc = _load(PMC_CFG4) or _load(os.path.join("profiles", "r01_pmc_summary_config4.json"))
     k = pmc and pmc["kernels"].get("k_trace_quad<false>")
     if k and k.get("hbm_bytes_per_frame"):

@@ -2,7 +2,7 @@
 """Not collected by pytest: a long randomized parity run on the GPU box.
 usage: python tests/campaign_fuzz.py FIRST LAST [WIDTH HEIGHT MAXREC]
 Every seed: tests/fuzz_scenes.random_scene rendered by re::HipRaytracer (BVH path; the reference kd-tree path every
-fourth seed; SSAA every eighth) against the genuine reference when oracle/_ref is built, else the C restatement: ids,
+fourth seed; SSAA every eighth) (odd seeds: BVHs built on the device) against the genuine reference when oracle/_ref is built, else the C restatement: ids,
 pixels and ray counts bit for bit.  Prints one line per mismatch and a progress line every 10 seeds; exit code 1 on
 any mismatch."""
 import os, sys, time
@@ -21,6 +21,7 @@ bad = 0
 t0 = time.time()
 for seed in range(first, last + 1):
     sd = random_scene(seed)
+    os.environ["RE_BVH_DEVICE_MIN_TRIS"] = "1" if seed % 2 else "0"   # odd seeds: every mesh's BVH is built on the device
     for aa in ((0, 1) if seed % 8 == 0 else (0,)):
         ref = sd.build(lib).render(W, H, ids=True, threads=16, max_recursion=MAXREC, aa=aa)
         for use_kd in ((False, True) if seed % 4 == 0 else (False,)):

@@ -1,4 +1,5 @@
-"""Seeded random scenes for the fuzz parity tests: spheres / planes / small meshes under nested nodes with random
+"""Seeded random scenes for the fuzz parity tests: spheres / planes / small meshes (bumpy grids, octahedra, soups of large
+overlapping triangles) under nested nodes with random
 rotation and non-uniform (sometimes extreme) scale, every light type, uniform and noise-interpolated materials,
 both backgrounds.  Everything derives from the seed through PCG32, so a failing seed reproduces anywhere."""
 import numpy as np
@@ -24,6 +25,12 @@ def _small_mesh(r, kind):
     if kind == 0:   # bumpy grid, vertex normals
         v, n = scenes.heightfield_mesh(cells=6 + r.i(6), seed=1 + r.i(1000), extent=1.0 + r.u(0, 2))
         return v, n, scenes.NORMAL_VERTEX
+    if kind == 2:   # a soup of a few LARGE random triangles that overlap and cross each other (round 2: found the quad walk's
+                    # stack one level short on BVHs that are a lone root), face or vertex normals
+        n_tris = 1 + r.i(24)
+        v = np.array([[r.u(-1.5, 1.5) for _ in range(9)] for _ in range(n_tris)])
+        n = np.array([[r.u(-1, 1) for _ in range(9)] for _ in range(n_tris)])
+        return v, n, scenes.NORMAL_VERTEX if r.i(2) else scenes.NORMAL_FACE
     # closed octahedron, face normals, outward winding
     p = np.array([[1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1]], dtype=np.float64)
     faces = [(0, 2, 4), (2, 1, 4), (1, 3, 4), (3, 0, 4), (2, 0, 5), (1, 2, 5), (3, 1, 5), (0, 3, 5)]
@@ -64,7 +71,7 @@ def random_scene(seed):
         if kind <= 1:
             sd.sphere(mat, node=node)
         elif kind == 2:
-            v, n, mode = _small_mesh(r, r.i(2))
+            v, n, mode = _small_mesh(r, r.i(3))
             sd.mesh(mat, v, n, mode, node=node)
         else:
             sd.plane(mat, r.u(-0.3, 0.3), 1, r.u(-0.3, 0.3), node=sd.node(-1, (0, r.u(-3, -1), 0), (0, 0, r.u(-0.1, 0.1)), (1, 1, 1)))
