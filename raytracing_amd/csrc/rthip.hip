@@ -93,7 +93,7 @@ static std::mutex g_scratch_mutex;
 #define RT_EASY_OCC 4
 #endif
 #ifndef RT_QUAD_OCC
-#define RT_QUAD_OCC 4
+#define RT_QUAD_OCC 5
 #endif
 #ifndef RT_SHADE_OCC
 #define RT_SHADE_OCC 4
@@ -568,42 +568,64 @@ __device__ __forceinline__ void mesh_closest(const SceneView &sv, const rthip_me
     }
 }
 
-// Scene::CastRay (Scene.cpp:163-237) for the quad's ray; same contract as rtc::cast_ray_id.
-template <bool COUNT>
+// The world-space ray a quad is casting is PARKED in LDS (behind the stacks, kParkStride bytes per quad) and read back
+// where it is needed: before each mesh (world -> local), after a walk (distance of the hit), for the hit details.  The
+// walk's loop then holds the mesh-local ray only; with the world ray (and the loop-carried copies a shared closest /
+// shadow code path needs) in registers the kernel took 128 VGPRs = 4 waves per SIMD, and a config-4 frame is 17 % slower
+// at 3 waves than at 4: it is resident waves that hide the dependent node fetches.  The stack stores of the walk may
+// alias the parked words as far as the compiler knows, so it cannot keep them in registers across a walk.
+static const uint32_t kParkStride = 112;  // bytes: 12 doubles, padded so that 16 quads' 16-byte reads fall in distinct banks
+__host__ __device__ __forceinline__ uint32_t park_offset(uint32_t stack_cap) {  // the stacks, rounded up to 16 bytes
+    return (kRaysPerBlock * (stack_cap + 1u) * 8u + 15u) & ~15u;
+}
+struct Park {
+    double *p;  // [0..2] origin, [3..5] direction
+    // all four lanes store (the same values to the same words): a lane then reads back what IT wrote, so nothing
+    // here depends on another lane's store being visible (the compiler reasons per thread and may forward a lane's
+    // own older value past a store it did not execute)
+    __device__ __forceinline__ void put_o(V3 o) const { p[0] = o.x; p[1] = o.y; p[2] = o.z; }
+    __device__ __forceinline__ void put_d(V3 d) const { p[3] = d.x; p[4] = d.y; p[5] = d.z; }
+    __device__ __forceinline__ V3 o() const { return mk(p[0], p[1], p[2]); }
+    __device__ __forceinline__ V3 d() const { return mk(p[3], p[4], p[5]); }
+};
+
+// Scene::CastRay (Scene.cpp:163-237) for the quad's parked ray; same contract as rtc::cast_ray_id.
 // `known`: the query over the analytic shapes has been answered already (k_trace_easy, closest-hit query only).
-__device__ __forceinline__ int32_t cast_ray(const SceneView &sv, V3 o, V3 d, Stack qs, uint32_t q, bool any_hit, bool active,
+template <bool COUNT>
+__device__ __forceinline__ int32_t cast_ray(const SceneView &sv, Park park, Stack qs, uint32_t q, bool any_hit, bool active,
                                             const PendRec *known, int32_t &best_tri, bool &redo, KdCounters &cnt) {
     double bd = known ? known->bd : DBL_MAX;
     uint32_t bs = known ? known->bs : 0xffffffffu;
     best_tri = -1;
     bool meshes = known != nullptr;  // (the quad kernel only runs on scenes with meshes)
-    // analytic shapes, one per lane and pass; the earlier node wins exact distance ties (Scene.cpp:225)
-    for (uint32_t s0 = 0; s0 < (known ? 0u : sv.n_shapes); s0 += 4) {
-        const uint32_t s = s0 + q;
-        if (!active || s >= sv.n_shapes) continue;
-        const rthip_shape &sh = sv.shapes[s];
-        const int32_t type = sh.type;
-        if (type == RTHIP_SHAPE_MESH) {
-            meshes = true;
-            continue;
+    if (!known) {
+        // analytic shapes, one per lane and pass; the earlier node wins exact distance ties (Scene.cpp:225)
+        const V3 o = park.o(), d = park.d();
+        for (uint32_t s0 = 0; s0 < sv.n_shapes; s0 += 4) {
+            const uint32_t s = s0 + q;
+            if (!active || s >= sv.n_shapes) continue;
+            const rthip_shape &sh = sv.shapes[s];
+            const int32_t type = sh.type;
+            if (type == RTHIP_SHAPE_MESH) {
+                meshes = true;
+                continue;
+            }
+            if (COUNT) cnt.shapes++;
+            if (type == RTHIP_SHAPE_SPHERE && ball_missed(sh.bound_c[0], sh.bound_c[1], sh.bound_c[2], sh.bound_r2, o, d)) continue;
+            V3 lo = xform(sh.inv, o, 1.0);
+            V3 ld = normalized(xform(sh.inv, d, 0.0));
+            V3 p;
+            bool hit = type == RTHIP_SHAPE_SPHERE ? sphere_intersect(lo, ld, p)
+                                                  : plane_intersect(mk(sh.plane_n[0], sh.plane_n[1], sh.plane_n[2]), lo, ld, p);
+            if (!hit) continue;
+            V3 worldPoint = xform(sh.fwd, p, 1.0);
+            double distance = sqlen(sub(o, worldPoint));
+            if (!(distance >= DBL_EPSILON)) continue;
+            if (!(distance < bd)) continue;
+            bd = distance;
+            bs = s;
         }
-        if (COUNT) cnt.shapes++;
-        if (type == RTHIP_SHAPE_SPHERE && ball_missed(sh.bound_c[0], sh.bound_c[1], sh.bound_c[2], sh.bound_r2, o, d)) continue;
-        V3 lo = xform(sh.inv, o, 1.0);
-        V3 ld = normalized(xform(sh.inv, d, 0.0));
-        V3 p;
-        bool hit = type == RTHIP_SHAPE_SPHERE ? sphere_intersect(lo, ld, p)
-                                              : plane_intersect(mk(sh.plane_n[0], sh.plane_n[1], sh.plane_n[2]), lo, ld, p);
-        if (!hit) continue;
-        V3 worldPoint = xform(sh.fwd, p, 1.0);
-        double distance = sqlen(sub(o, worldPoint));
-        if (!(distance >= DBL_EPSILON)) continue;
-        if (!(distance < bd)) continue;
-        bd = distance;
-        bs = s;
-    }
-    if (!known) reduce_min(bd, bs);
-    {
+        reduce_min(bd, bs);
         uint32_t mm = meshes ? 1u : 0u;
         mm |= dpp<kXor1>(mm);
         mm |= dpp<kXor2>(mm);
@@ -616,29 +638,39 @@ __device__ __forceinline__ int32_t cast_ray(const SceneView &sv, V3 o, V3 d, Sta
         if (sh->type != RTHIP_SHAPE_MESH) continue;
         if (!active || redo || (any_hit && bs != 0xffffffffu)) continue;
         if (COUNT) cnt.shapes += (q == 0);
-        if (ball_missed(sh->bound_c[0], sh->bound_c[1], sh->bound_c[2], sh->bound_r2, o, d)) continue;
-        double inv[12], fwd[12];
+        V3 lo, ld;
+        float t_stop = 3.0e38f;
+        {
+            const V3 o = park.o(), d = park.d();
+            if (ball_missed(sh->bound_c[0], sh->bound_c[1], sh->bound_c[2], sh->bound_r2, o, d)) continue;
+            double inv[12];
 #pragma unroll
-        for (int k = 0; k < 12; k++) {
-            inv[k] = sh->inv[k];
-            fwd[k] = sh->fwd[k];
+            for (int k = 0; k < 12; k++) inv[k] = sh->inv[k];
+            lo = xform(inv, o, 1.0);
+            ld = normalized(xform(inv, d, 0.0));
         }
-        V3 lo = xform(inv, o, 1.0);
-        V3 ld = normalized(xform(inv, d, 0.0));
         const rthip_mesh m = rt_load_mesh(sv.meshes + sh->mesh);
         if (kd_degenerate_ray(sv, m, lo, ld)) {
             redo = true;
             continue;
         }
-        const float t_stop = any_hit ? anyhit_t_stop(fwd, sh->rt_lin, sh->rt_t, o, ld) : 3.0e38f;
+        if (any_hit) {
+            double fwd[12];
+#pragma unroll
+            for (int k = 0; k < 12; k++) fwd[k] = sh->fwd[k];
+            t_stop = anyhit_t_stop(fwd, sh->rt_lin, sh->rt_t, park.o(), ld);
+        }
         TriBest tb;
         mesh_closest<COUNT>(sv, m, lo, ld, qs, q, t_stop, tb, cnt);
         if (!tb.hit) continue;
         V3 p;
         double u, v, w;
         tri_point(sv.tris[m.tri_base + tb.tri], lo, ld, p, u, v, w);
+        double fwd[12];
+#pragma unroll
+        for (int k = 0; k < 12; k++) fwd[k] = sh->fwd[k];
         V3 worldPoint = xform(fwd, p, 1.0);
-        double distance = sqlen(sub(o, worldPoint));
+        double distance = sqlen(sub(park.o(), worldPoint));
         if (!(distance >= DBL_EPSILON)) continue;
         if (distance < bd || (distance == bd && s < bs)) {
             bd = distance;
@@ -649,59 +681,52 @@ __device__ __forceinline__ int32_t cast_ray(const SceneView &sv, V3 o, V3 d, Sta
     return (int32_t)bs;
 }
 
-// rtc::trace_stage for the quad's ray
-template <bool COUNT>
+// rtc::trace_stage for the quad's ray (parked by the caller).
 // The hit record is stored as soon as the closest query is resolved (mask 0), so that the local point and the
 // normal do not stay in registers through the shadow walks; the caller patches the shadow mask in afterwards.
-__device__ __forceinline__ bool trace_stage(const SceneView &sv, V3 o, V3 d, uint32_t n_shadow_lights, Stack qs, uint32_t q,
+template <bool COUNT>
+__device__ __forceinline__ bool trace_stage(const SceneView &sv, Park park, uint32_t n_shadow_lights, Stack qs, uint32_t q,
                                             bool live, const Work &w, uint32_t i, const PendRec &analytic, int32_t &out_shape,
                                             int32_t &out_tri, uint32_t &out_mask, KdCounters &cnt) {
     bool redo = false;
-    struct {
-        int32_t shape, tri;
-        uint32_t shadow_mask;
-    } h = {-1, -1, 0u};
-    V3 point = mk(0, 0, 0);
-    for (int32_t l = -1; l < (int32_t)n_shadow_lights; l++) {
-        V3 ro = o, rd = d;
-        bool active = live && !redo;
-        if (l >= 0) {
-            const rt_uniform_light *light = rt_uniform_cast(sv.lights) + l;
-            const int32_t ltype = light->type;
-            if (!light->enabled || ltype == RTHIP_LIGHT_AMBIENT) continue;  // Raytracer.cpp:213, 234-237
-            active = active && h.shape >= 0;
-            ro = point;
-            if (ltype == RTHIP_LIGHT_DIRECTIONAL)
-                rd = mk(light->direction[0], light->direction[1], light->direction[2]);
-            else
-                rd = normalized(sub(mk(light->position[0], light->position[1], light->position[2]), point));
-        }
+    out_shape = -1;
+    out_tri = -1;
+    out_mask = 0u;
+    {   // the closest hit
         int32_t tri;
-        const int32_t shape = cast_ray<COUNT>(sv, ro, rd, qs, q, l >= 0, active, l < 0 ? &analytic : nullptr, tri, redo, cnt);
-        if (l < 0) {
-            if (shape >= 0 && !redo) {
-                Hit c;
-                hit_details(sv, o, d, shape, tri, c, (COUNT && q == 0) ? &cnt : nullptr);
-                h.shape = shape;
-                h.tri = tri;
-                point = c.point;
-                if (q == 0) {
-                    HitRec rec;
-                    rec.shape = shape;
-                    rec.tri = tri;
-                    rec.shadow_mask = 0;
-                    rec.local = c.local;
-                    rec.normal = c.normal;
-                    store_hit(w, i, rec);
-                }
+        const int32_t shape = cast_ray<COUNT>(sv, park, qs, q, false, live, &analytic, tri, redo, cnt);
+        if (shape >= 0 && !redo) {
+            Hit c;
+            hit_details(sv, park.o(), park.d(), shape, tri, c, (COUNT && q == 0) ? &cnt : nullptr);
+            out_shape = shape;
+            out_tri = tri;
+            if (q == 0) {
+                HitRec rec;
+                rec.shape = shape;
+                rec.tri = tri;
+                rec.shadow_mask = 0;
+                rec.local = c.local;
+                rec.normal = c.normal;
+                store_hit(w, i, rec);
             }
-        } else if (shape >= 0) {
-            h.shadow_mask |= 1u << l;
+            park.put_o(c.point);  // every shadow ray starts there
         }
     }
-    out_shape = h.shape;
-    out_tri = h.tri;
-    out_mask = h.shadow_mask;
+    for (uint32_t l = 0; l < n_shadow_lights; l++) {
+        const rt_uniform_light *light = rt_uniform_cast(sv.lights) + l;
+        const int32_t ltype = light->type;
+        if (!light->enabled || ltype == RTHIP_LIGHT_AMBIENT) continue;  // Raytracer.cpp:213, 234-237
+        const bool active = live && !redo && out_shape >= 0;
+        V3 rd;
+        if (ltype == RTHIP_LIGHT_DIRECTIONAL)
+            rd = mk(light->direction[0], light->direction[1], light->direction[2]);
+        else
+            rd = normalized(sub(mk(light->position[0], light->position[1], light->position[2]), park.o()));
+        park.put_d(rd);
+        int32_t tri;
+        const int32_t shape = cast_ray<COUNT>(sv, park, qs, q, true, active, nullptr, tri, redo, cnt);
+        if (shape >= 0) out_mask |= 1u << l;
+    }
     return !redo;
 }
 }  // namespace quad
@@ -1010,6 +1035,8 @@ __global__ __launch_bounds__(kBlock, RT_QUAD_OCC) void k_trace_quad(SceneView sv
     quad::Stack qs;
     qs.cap = stack_cap;
     qs.e = reinterpret_cast<uint2 *>(lds_dyn) + g * (stack_cap + 1u);
+    quad::Park park;
+    park.p = reinterpret_cast<double *>(reinterpret_cast<char *>(lds_dyn) + quad::park_offset(stack_cap) + g * quad::kParkStride);
     const uint32_t n = min(w.N, w.hard_count[0]);
     const uint32_t n_shadow = fp.renderer == RTHIP_RENDER_RAYTRACER ? sv.n_lights : 0u;  // DebugRaycaster: closest hit only
     KdCounters kc = {0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -1023,13 +1050,17 @@ __global__ __launch_bounds__(kBlock, RT_QUAD_OCC) void k_trace_quad(SceneView sv
         bool live = j < n;
         const uint32_t i = live ? w.hard[j] : 0u;
         const uint32_t nodes_before = kc.nodes;
-        V3 o = mk(0, 0, 0), d = mk(0, 0, 1);
         uint32_t pix_slot = 0;
         if (level == 0) pix_slot = i % fp.n_pix_slots;
-        if (live) {  // level 0 too: k_trace_easy has stored the primary rays it listed
-            const RayRec r = ray_at(w, level, i);
-            o = mk(r.ox, r.oy, r.oz);
-            d = mk(r.dx, r.dy, r.dz);
+        {   // level 0 too: k_trace_easy has stored the primary rays it listed
+            V3 o = mk(0, 0, 0), d = mk(0, 0, 1);
+            if (live) {
+                const RayRec r = ray_at(w, level, i);
+                o = mk(r.ox, r.oy, r.oz);
+                d = mk(r.dx, r.dy, r.dz);
+            }
+            park.put_o(o);
+            park.put_d(d);
         }
         int32_t hit_shape, hit_tri;
         uint32_t shadow_mask;
@@ -1038,7 +1069,7 @@ __global__ __launch_bounds__(kBlock, RT_QUAD_OCC) void k_trace_quad(SceneView sv
         analytic.bs = 0xffffffffu;
         analytic.pad = 0;
         if (live) analytic = w.pend[j];
-        const bool done = quad::trace_stage<COUNT>(sv, o, d, n_shadow, qs, q, live, w, i, analytic, hit_shape, hit_tri, shadow_mask, kc);
+        const bool done = quad::trace_stage<COUNT>(sv, park, n_shadow, qs, q, live, w, i, analytic, hit_shape, hit_tri, shadow_mask, kc);
         if (!live || q != 0) continue;
         if (COUNT && kc.nodes - nodes_before > max_ray_nodes) max_ray_nodes = kc.nodes - nodes_before;
         if (!done) {
@@ -1879,8 +1910,8 @@ static int render_frame(rthip_ctx *c, const rthip_camera *cam, uint32_t n_frames
     // cannot overflow, see quad::Stack: the deepest node is bvh_depth levels below the root, so a path makes bvh_depth + 1 steps
     // of at most three pushes (3 * depth + 1 was one level short: a mesh whose BVH is a lone root overflowed with two pushes)
     const uint32_t quad_cap = 3 * (c->bvh_depth + 1);
-    const size_t lds_quad = (size_t)quad::kRaysPerBlock * (quad_cap + 1) * sizeof(uint2);
-    if (lds_quad > 64 * 1024) {
+    const size_t lds_quad = (size_t)quad::park_offset(quad_cap) + (size_t)quad::kRaysPerBlock * quad::kParkStride;
+    if (lds_quad > 48 * 1024) {
         HIP_TRY(hipFuncSetAttribute((const void *)k_trace_quad<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_quad));
         HIP_TRY(hipFuncSetAttribute((const void *)k_trace_quad<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_quad));
     }

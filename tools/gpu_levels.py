@@ -1,30 +1,34 @@
 #!/usr/bin/env python3
-"""Per-level diagnostics on the GPU: rays per level, trace-kernel time per level, worst single-ray node count."""
+"""Per recursion level of a config's lone frame: rays in the queue, duration of the mesh-walk kernel, of k_trace_easy and
+of the shade kernels (RTHIP_PROFILE_LAUNCHES=1), and with RTHIP_COUNTERS=1 the walk's step / wave-step counters per level
+(one frame rendered per MaxRecursion 0..MR, counters differenced)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+counters = len(sys.argv) > 2 and sys.argv[2] == "counters"
 os.environ["RTHIP_PROFILE_LAUNCHES"] = "1"
-from raytracing_amd import device, host, scenes
+if counters: os.environ["RTHIP_COUNTERS"] = "1"
+os.environ.setdefault("RE_BVH_DEVICE_MIN_TRIS", "0")
 import torch
-cfgs = [int(a) for a in sys.argv[1:]] or [3, 4]
-for cfg in cfgs:
-    sd, kw = scenes.config(cfg)
-    hs = host.HostScene(sd)
-    desc = hs.flatten()
-    W, H, mr = kw["width"], kw["height"], kw["max_recursion"]
-    cam = hs.camera(W, H)
-    fb = torch.zeros(W * H, dtype=torch.int32, device="cuda")
-    for counters, mrr in [("0", mr), ("0", 0), ("1", mr), ("2", mr)]:
-        prm = device.make_params(W, H, mrr)
-        os.environ["RTHIP_COUNTERS"] = counters
-        ctx = device.Context(0); ctx.upload(desc)
-        for i in range(3):
-            ctx.render_device(cam, prm, fb.data_ptr(), sync=True)
-        s = ctx.stats()
-        print(f"cfg{cfg} maxrec={mrr} counters={counters} ms_total={s.ms_total:.3f} ms_trace={s.ms_trace:.3f} max_nodes_ray={s.kd_max_nodes_ray} "
-              f"nodes={s.kd_nodes_visited} tris={s.kd_tris_tested} leaves={s.kd_leaves_visited} pops={s.kd_pops}\n"
-              f"   wave steps max={s.wave_steps_max} total={s.wave_steps}  wave tri-iters max={s.wave_tris_max} total={s.wave_tris}  longest wave {s.wave_cycles_max} cycles; node-fetch wait {s.fetch_cycles} cycles = {s.fetch_cycles / max(1, s.wave_steps):.0f}/step")
-        print("   level rays:", list(s.level_rays[:mr + 1]))
-        print("   easy ms   :", [round(x, 3) for x in s.level_ms_easy[:mr + 1]], " hard rays:", s.rays_hard)
-        print("   quad ms   :", [round(x, 3) for x in s.level_ms_trace[:mr + 1]])
-        print("   shade ms  :", [round(x, 3) for x in s.level_ms_shade[:mr + 1]], flush=True)
-        ctx.close()
+from raytracing_amd import device, host, scenes
+sd, kw = scenes.config(cfg)
+W, H, MR = kw["width"], kw["height"], kw["max_recursion"]
+hs = host.HostScene(sd); ctx = device.Context(0); ctx.upload(hs.flatten())
+fb = torch.zeros(W * H, dtype=torch.int32, device="cuda")
+cam = hs.camera(W, H)
+prev = None
+for mr in (range(MR + 1) if counters else (MR,)):
+    prm = device.make_params(W, H, mr)
+    for _ in range(2): ctx.render_device(cam, prm, fb.data_ptr(), sync=True)
+    s = ctx.stats()
+    if not counters:
+        print(f"cfg {cfg}: ms_total {s.ms_total:.3f} trace {s.ms_trace:.3f} easy {s.ms_easy:.3f} hard {s.rays_hard}")
+        for l in range(mr + 1):
+            print(f"  level {l}: rays {s.level_rays[l]:9d} walk {s.level_ms_trace[l]:.3f} ms easy {s.level_ms_easy[l]:.3f} ms shade+redo {s.level_ms_shade[l]:.3f} ms")
+    else:
+        cur = dict(hard=s.rays_hard, steps=s.kd_nodes_visited, wsteps=s.wave_steps, leaves=s.kd_leaves_visited, wtris=s.wave_tris, tris=s.kd_tris_tested)
+        d = {k: cur[k] - (prev[k] if prev else 0) for k in cur}
+        print(f"  level {mr}: hard {d['hard']:9d} steps {d['steps']:10d} ({d['steps'] / max(1, d['hard']):.1f}/ray) wave steps {d['wsteps']:9d} "
+              f"(quads active per wave step {d['steps'] / max(1, d['wsteps']):.2f}/16) leaves {d['leaves']} wave leaf iterations {d['wtris']} "
+              f"({d['leaves'] / max(1, d['wtris']):.2f}/16) tris {d['tris']}", flush=True)
+        prev = cur
