@@ -159,10 +159,12 @@ template <class TriView> struct KdBuilder {
         return me;
     }
 };
-// Binned-SAH binary BVH (16 bins, 3 axes), then collapsed to 4-wide nodes.  Boxes are exact fp64 while
-// building and rounded OUTWARD (plus one ulp) to fp32 when stored, so the device's fp32 slab test stays
-// conservative.  Leaves hold 1..4 triangles: the four lanes that trace a ray test them in one step, so a
-// group of <= 4 triangles is never split further.
+// Binned-SAH binary BVH (16 bins, 3 axes) down to single triangles, then collapsed to 4-wide nodes with leaves of
+// 1..4 triangles (the four lanes that trace a ray test a leaf in one step).  The collapse is the optimal one for the
+// binary topology under the surface-area cost (dynamic programme over "this subtree as a forest of at most i wide
+// sub-trees", i = 1..3, Ylitie, Karras, Laine 2017, section 3.1): a greedy "open the largest child" collapse over
+// leaves fixed at <= 4 triangles gave 2.8 children per node on a 2M-triangle height field.  Boxes are exact fp64 while
+// building and rounded OUTWARD (plus one ulp) to fp32 when stored, so the device's fp32 slab test stays conservative.
 template <class TriView> struct BvhBuilder {
     static constexpr int kBins = 16;
     static constexpr uint32_t kMaxLeaf = RTHIP_BVH_MAX_LEAF;
@@ -177,11 +179,15 @@ template <class TriView> struct BvhBuilder {
             return dx < 0 ? 0.0 : 2 * (dx * dy + dx * dz + dy * dz);
         }
     };
-    struct Node2 { Box b[2]; uint32_t c[2]; };
+    struct Node2 { Box b[2]; uint32_t c[2]; uint32_t first, count; };  // children: boxes and words (a leaf word holds ONE triangle); the node's range of `order`
+    struct Plan { double c[3]; uint8_t k[3]; uint8_t leaf; };  // c[i-1]: cost as a forest of <= i trees; k[0]: how many of an interior node's 4 slots the left child takes;
+                                                               // k[i-1], i = 2, 3: left share of the forest, 0 = no better than i - 1 trees; leaf: as ONE tree it is a leaf
     const TriView &tris;
     BvhFlat &out;
     std::vector<double> tlo, thi, cen;  // 3 per triangle
     std::vector<Node2> bin;             // the binary tree
+    std::vector<Plan> plan;
+    double leaf_cost = 1.5;  // a triangle step (<= 4 fp64 tests, 128 B each) against a node step (4 fp32 slab tests, 128 B)
     static constexpr uint32_t kTaskMin = 1u << 15;  // triangles below which a sub-tree is not worth a thread
 
     static float Down(double x) {
@@ -228,7 +234,7 @@ template <class TriView> struct BvhBuilder {
         box = BoundsOf(lo, hi);
         const uint32_t n = hi - lo;
         auto leaf = [&]() { return RTHIP_BVH_LEAF | ((n - 1) << RTHIP_BVH_COUNT_SHIFT) | lo; };
-        if (n <= kMaxLeaf) return leaf();
+        if (n <= 1) return leaf();
         Box cb;  // centroid bounds
         for (uint32_t i = lo; i < hi; i++) cb.Grow(&cen[3 * out.order[i]], &cen[3 * out.order[i]]);
         int best_axis = -1, best_bin = 0;
@@ -320,24 +326,63 @@ template <class TriView> struct BvhBuilder {
         }
         bin[me].b[0] = b0; bin[me].b[1] = b1;
         bin[me].c[0] = c0; bin[me].c[1] = c1;
+        bin[me].first = lo; bin[me].count = n;
         return me;
     }
-    // 4-wide node from the binary node n2: repeatedly open the interior child with the largest box
-    uint32_t Collapse(uint32_t n2, unsigned depth) {
-        struct Item { uint32_t c; Box b; };
-        Item items[4] = {{bin[n2].c[0], bin[n2].b[0]}, {bin[n2].c[1], bin[n2].b[1]}};
-        int n = 2;
-        while (n < 4) {
-            int pick = -1;
-            double area = -1;
-            for (int i = 0; i < n; i++)
-                if (!(items[i].c & RTHIP_BVH_LEAF) && items[i].b.Area() > area) { area = items[i].b.Area(); pick = i; }
-            if (pick < 0) break;
-            const Node2 &o = bin[items[pick].c];
-            const Item a = {o.c[0], o.b[0]}, b = {o.c[1], o.b[1]};
-            items[pick] = a;
-            items[n++] = b;
+    double CostOf(uint32_t word, const Box &b, int i) const {
+        return (word & RTHIP_BVH_LEAF) ? b.Area() * leaf_cost : plan[word].c[i - 1];
+    }
+    // bottom-up: the cheapest way to stand for the binary subtree n2 as at most i wide sub-trees
+    void Solve(uint32_t n2) {
+        const Node2 &o = bin[n2];
+        for (int s = 0; s < 2; s++)
+            if (!(o.c[s] & RTHIP_BVH_LEAF)) Solve(o.c[s]);
+        Box me = o.b[0];
+        me.Grow(o.b[1]);
+        double dist[5];
+        uint8_t at[5];
+        for (int j = 2; j <= 4; j++) {
+            dist[j] = 1e300;
+            at[j] = 1;
+            for (int k = 1; k < j; k++) {
+                const double c = CostOf(o.c[0], o.b[0], std::min(k, 3)) + CostOf(o.c[1], o.b[1], std::min(j - k, 3));
+                if (c < dist[j]) { dist[j] = c; at[j] = (uint8_t)k; }
+            }
         }
+        Plan p;
+        const double interior = dist[4] + me.Area(), as_leaf = o.count <= kMaxLeaf ? me.Area() * leaf_cost : 1e300;
+        p.leaf = as_leaf <= interior;
+        p.c[0] = p.leaf ? as_leaf : interior;
+        p.k[0] = at[4];
+        for (int i = 2; i <= 3; i++) {
+            const bool better = dist[i] < p.c[i - 2];
+            p.c[i - 1] = better ? dist[i] : p.c[i - 2];
+            p.k[i - 1] = better ? at[i] : 0;
+        }
+        plan[n2] = p;
+    }
+    struct Item { uint32_t c; Box b; };
+    // the roots of the planned forest of at most i trees for `word`, appended to items
+    void Forest(uint32_t word, const Box &box, int i, Item *items, int &n) const {
+        if (!(word & RTHIP_BVH_LEAF)) {
+            const Plan &p = plan[word];
+            i = std::min(i, 3);
+            while (i > 1 && p.k[i - 1] == 0) i--;
+            if (i > 1) {
+                Forest(bin[word].c[0], bin[word].b[0], p.k[i - 1], items, n);
+                Forest(bin[word].c[1], bin[word].b[1], i - p.k[i - 1], items, n);
+                return;
+            }
+        }
+        items[n].c = word;
+        items[n++].b = box;
+    }
+    // 4-wide node for the binary node n2 (planned as an interior node)
+    uint32_t Collapse(uint32_t n2, unsigned depth) {
+        Item items[4];
+        int n = 0;
+        Forest(bin[n2].c[0], bin[n2].b[0], plan[n2].k[0], items, n);
+        Forest(bin[n2].c[1], bin[n2].b[1], 4 - plan[n2].k[0], items, n);
         const uint32_t me = (uint32_t)out.nodes.size();
         out.nodes.emplace_back();
         out.depth = std::max(out.depth, depth);
@@ -346,7 +391,10 @@ template <class TriView> struct BvhBuilder {
             std::memset(&ch, 0, sizeof ch);
             if (i < n) {
                 for (int a = 0; a < 3; a++) { ch.lo[a] = Down(items[i].b.lo[a]); ch.hi[a] = Up(items[i].b.hi[a]); }
-                ch.child = (items[i].c & RTHIP_BVH_LEAF) ? items[i].c : Collapse(items[i].c, depth + 1);
+                const uint32_t c = items[i].c;
+                if (c & RTHIP_BVH_LEAF) ch.child = c;
+                else if (plan[c].leaf) ch.child = RTHIP_BVH_LEAF | ((bin[c].count - 1) << RTHIP_BVH_COUNT_SHIFT) | bin[c].first;
+                else ch.child = Collapse(c, depth + 1);
             } else {
                 for (int a = 0; a < 3; a++) { ch.lo[a] = INFINITY; ch.hi[a] = -INFINITY; }
                 ch.child = RTHIP_BVH_ABSENT;
@@ -358,9 +406,15 @@ template <class TriView> struct BvhBuilder {
     void Run() {
         out = BvhFlat();
         if (tris.empty()) return;
+        if (const char *e = std::getenv("RE_BVH_LEAF_COST")) leaf_cost = std::atof(e);  // tuning experiments
         Prepare();
         Box root;
-        const uint32_t w = Build(bin, 0, (uint32_t)tris.size(), 0, root, BuildForkDepth());
+        uint32_t w = Build(bin, 0, (uint32_t)tris.size(), 0, root, BuildForkDepth());
+        if (!(w & RTHIP_BVH_LEAF)) {
+            plan.resize(bin.size());
+            Solve(w);
+            if (plan[w].leaf) w = RTHIP_BVH_LEAF | ((bin[w].count - 1) << RTHIP_BVH_COUNT_SHIFT) | bin[w].first;
+        }
         if (w & RTHIP_BVH_LEAF) {  // tiny mesh: a root node whose only child is the single leaf
             out.nodes.emplace_back();
             for (int i = 0; i < 4; i++) {
@@ -377,6 +431,7 @@ template <class TriView> struct BvhBuilder {
             Collapse(w, 0);
         }
         std::vector<Node2>().swap(bin);
+        std::vector<Plan>().swap(plan);
     }
 };
 }  // namespace rtbuild
