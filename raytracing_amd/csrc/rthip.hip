@@ -543,10 +543,11 @@ __device__ __forceinline__ void mesh_closest(const SceneView &sv, const rthip_me
             double dd = DBL_MAX;
             uint32_t ti = 0xffffffffu;
             if (q < count) {
+                const uint32_t id = index[first + q];  // fetched with the triangle, not after the test: one round trip per leaf step
                 double e;
                 if (tri_eval(tris[first + q], o, d, e)) {
                     dd = e;
-                    ti = index[first + q];
+                    ti = id;
                 }
             }
             reduce_min(dd, ti);
