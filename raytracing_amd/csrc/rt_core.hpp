@@ -376,13 +376,20 @@ RT_HD bool plane_intersect(V3 n, V3 o, V3 d, V3 &point) {
 struct TriBest {
     double d;      // |O - P|^2 exactly as Scene.cpp:477
     uint32_t tri;  // mesh-relative triangle index
-    uint32_t ref;  // position in the pre-order leaf-reference array (tie order)
+    uint32_t ref;  // position in the pre-order leaf-reference array (kd walk) / the triangle index (BVH walk)
     bool hit;
+    bool tie;      // another triangle was accepted at exactly the distance `d` (see mesh_closest_reference_order)
 };
 
 // Scene.cpp:421-467 IntersectTriangle + :495-507 Baricentric: plane projection, back-face /
-// behind-plane cull, inclusive barycentric test.  Updates `best` with the strict '<' of Scene.cpp:479
-// (exact ties keep the candidate that comes first in the reference's pre-order walk).
+// behind-plane cull, inclusive barycentric test.  Updates `best` with the strict '<' of Scene.cpp:479.
+// EXACT TIES (two triangles accepted at bit-identical d, e.g. a ray through the shared diagonal of an
+// axis-aligned quad): the reference keeps the one its walk tests first, and that order - leaves in
+// pre-order, Left before Right (Scene.cpp:486-490), a straddling triangle at its first VISITED leaf - is
+// a property of the ray and the tree, not of the triangle index or of the reference position alone (a
+// pruned or reordered walk may never see the earlier instance).  So the fast walks only DETECT a tie at
+// the winning distance (`best.tie`; any provisional winner) and closest-hit queries that end with one are
+// repeated by mesh_closest_reference_order, which is the reference's walk itself.
 RT_HD void tri_test(const rthip_tri &t, V3 o, V3 d, uint32_t tri, uint32_t ref, TriBest &best) {
     V3 v0 = mk(t.v0[0], t.v0[1], t.v0[2]);
     V3 nf = mk(t.face_normal[0], t.face_normal[1], t.face_normal[2]);
@@ -400,7 +407,9 @@ RT_HD void tri_test(const rthip_tri &t, V3 o, V3 d, uint32_t tri, uint32_t ref, 
     double u = 1.0 - v - w;
     if (u >= 0 && v >= 0 && w >= 0) {
         double dd = sqlen(sub(o, projection));
+        if (best.hit && dd == best.d && tri != best.tri) best.tie = true;
         if (dd < best.d || (best.hit && dd == best.d && ref < best.ref)) {
+            if (dd < best.d) best.tie = false;
             best.d = dd;
             best.tri = tri;
             best.ref = ref;
@@ -409,8 +418,8 @@ RT_HD void tri_test(const rthip_tri &t, V3 o, V3 d, uint32_t tri, uint32_t ref, 
     }
 }
 
-// Same test for the BVH walk: the mesh-relative triangle index (tie order: the lower index comes
-// first in the reference's walk) is only fetched for accepted hits.
+// Same test for the BVH walk; the mesh-relative triangle index is only fetched for accepted hits.  On an exact tie
+// the lower index is kept provisionally and `best.tie` is raised (see tri_test).
 RT_HD void tri_test_bvh(const rthip_tri &t, V3 o, V3 d, const uint32_t *index, uint32_t pos, TriBest &best) {
     V3 v0 = mk(t.v0[0], t.v0[1], t.v0[2]);
     V3 nf = mk(t.face_normal[0], t.face_normal[1], t.face_normal[2]);
@@ -430,7 +439,9 @@ RT_HD void tri_test_bvh(const rthip_tri &t, V3 o, V3 d, const uint32_t *index, u
         double dd = sqlen(sub(o, projection));
         if (dd <= best.d) {
             uint32_t ti = index[pos];
+            if (best.hit && dd == best.d && ti != best.tri) best.tie = true;
             if (dd < best.d || (best.hit && ti < best.tri)) {
+                if (dd < best.d) best.tie = false;
                 best.d = dd;
                 best.tri = ti;
                 best.ref = ti;
@@ -488,6 +499,7 @@ RT_HD bool kd_prunable(double t7, const TriBest &best) {
 RT_HD void mesh_closest(const SceneView &sv, const rthip_mesh &m, V3 o, V3 d, KdStack &st, TriBest &best,
                                  KdCounters *cnt) {
     best.hit = false;
+    best.tie = false;
     best.d = DBL_MAX;
     best.tri = 0xffffffffu;
     best.ref = 0xffffffffu;
@@ -566,6 +578,66 @@ RT_HD void mesh_closest(const SceneView &sv, const rthip_mesh &m, V3 o, V3 d, Kd
     }
 }
 
+// Mesh::IntersectInternal as written (Scene.cpp:469-493): every node whose box passes BoundingBox::Intersect, Left
+// subtree before Right, the triangles of a leaf in reference order, strict '<' - no reordering, no pruning.  Only
+// queries whose fast walk ended in an exact tie come here (a handful of rays per frame at most), so that the
+// triangle returned is the one the reference returns (its id, and with vertex normals its normal).
+RT_HD void mesh_closest_reference_order(const SceneView &sv, const rthip_mesh &m, V3 o, V3 d, KdStack &st, TriBest &best) {
+    best.hit = false;
+    best.tie = false;
+    best.d = DBL_MAX;
+    best.tri = 0xffffffffu;
+    best.ref = 0xffffffffu;
+    if (m.node_count == 0) return;
+    const rthip_kdnode *nodes = sv.kd_nodes + m.node_base;
+    const double *bounds = sv.kd_bounds + 6 * (size_t)m.node_base;
+    const uint32_t *refs = sv.kd_refs + m.ref_base;
+    const rthip_tri *tris = sv.tris + m.tri_base;
+    double t[6], t7;
+    slab_params(bounds, o, d, t);
+    if (!slab_hit(t, t7)) return;
+    st.clear();
+    uint32_t cur = 0;
+    for (;;) {
+        const rthip_kdnode nd = nodes[cur];
+        bool descend = false;
+        if (nd.info & RTHIP_KD_LEAF) {
+            const uint32_t count = nd.info >> RTHIP_KD_COUNT_SHIFT;
+            for (uint32_t i = 0; i < count; i++) {
+                const uint32_t ti = refs[nd.link + i];
+                TriBest one;
+                one.hit = false;
+                one.tie = false;
+                one.d = DBL_MAX;
+                one.tri = one.ref = 0xffffffffu;
+                tri_test(tris[ti], o, d, ti, nd.link + i, one);
+                if (one.hit && one.d < best.d) best = one;  // Scene.cpp:479
+            }
+        } else {
+            bool hl = false, hr = false;
+            if (nd.info & RTHIP_KD_HAS_LEFT) {
+                slab_params(bounds + 6 * (size_t)(cur + 1), o, d, t);
+                hl = slab_hit(t, t7);
+            }
+            if (nd.info & RTHIP_KD_HAS_RIGHT) {
+                slab_params(bounds + 6 * (size_t)nd.link, o, d, t);
+                hr = slab_hit(t, t7);
+            }
+            if (hl) {
+                if (hr) st.push(nd.link);
+                cur = cur + 1;
+                descend = true;
+            } else if (hr) {
+                cur = nd.link;
+                descend = true;
+            }
+        }
+        if (descend) continue;
+        if (st.empty()) break;
+        cur = st.pop();
+    }
+}
+
 // T4 through the device-oriented BVH: same result as mesh_closest (argmin over the mesh's triangles
 // of the reference's d = |O-P|^2 with the reference's triangle test), different culling structure.
 // Box tests are fp32 and CONSERVATIVE — child boxes are stored rounded outward, and every slab interval
@@ -638,6 +710,7 @@ template <bool COUNT>
 RT_HD void mesh_closest_bvh(const SceneView &sv, const rthip_mesh &m, V3 o, V3 d, KdStack &st, TriBest &best,
                             float t_stop, KdCounters *cnt) {
     best.hit = false;
+    best.tie = false;
     best.d = DBL_MAX;
     best.tri = 0xffffffffu;
     best.ref = 0xffffffffu;
@@ -749,6 +822,9 @@ RT_HD bool shape_intersect(const SceneView &sv, int32_t type, int32_t mesh, V3 p
         mesh_closest_bvh<COUNT>(sv, m, lo, ld, st, tb, t_stop, cnt);
     else
         mesh_closest(sv, m, lo, ld, st, tb, cnt);
+    // an exact tie at the winning distance: which triangle wins is the reference walk's business (a shadow query
+    // only consumes the distance: t_stop < 3e38 marks it)
+    if (tb.hit && tb.tie && !(t_stop < 3.0e38f)) mesh_closest_reference_order(sv, m, lo, ld, st, tb);
     if (!tb.hit) return false;
     tri = (int32_t)tb.tri;
     double u, v, w;

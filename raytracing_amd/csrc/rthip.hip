@@ -417,6 +417,16 @@ __device__ __forceinline__ void reduce_min(double &d, uint32_t &id) {
         if (od < d || (od == d && oi < id)) { d = od; id = oi; }
     }
 }
+// the same, and `tie` is raised (in all four lanes) when two lanes hold different ids at the winning d
+__device__ __forceinline__ void reduce_min_tie(double &d, uint32_t &id, bool &tie) {
+    const double d0 = d;
+    const uint32_t id0 = id;
+    reduce_min(d, id);
+    uint32_t t = (id0 != 0xffffffffu && d0 == d && id0 != id) ? 1u : 0u;  // this lane lost at equal distance
+    t |= dpp<kXor1>(t);
+    t |= dpp<kXor2>(t);
+    tie = t != 0u;
+}
 
 // Scene.cpp:421-467 + :495-507 for one triangle: accepted? and the reference's d = |O - P|^2
 __device__ __forceinline__ bool tri_eval(const rthip_tri &t, V3 o, V3 d, double &dd) {
@@ -476,6 +486,7 @@ template <bool COUNT>
 __device__ __forceinline__ void mesh_closest(const SceneView &sv, const rthip_mesh &m, V3 o, V3 d, Stack qs, uint32_t q,
                                              float t_stop, TriBest &best, KdCounters &cnt) {
     best.hit = false;
+    best.tie = false;
     best.d = DBL_MAX;
     best.tri = 0xffffffffu;
     best.ref = 0xffffffffu;
@@ -550,9 +561,14 @@ __device__ __forceinline__ void mesh_closest(const SceneView &sv, const rthip_me
                     ti = id;
                 }
             }
-            reduce_min(dd, ti);
-            // strict '<' of Scene.cpp:479; exact ties keep the triangle that comes first in the reference's walk
+            bool leaf_tie;
+            reduce_min_tie(dd, ti, leaf_tie);
+            // strict '<' of Scene.cpp:479.  Two different triangles accepted at the same distance: the lower index is kept
+            // for now and the tie recorded - a closest-hit query that ends with one goes to the redo kernel, whose walk
+            // settles it in the reference's order (rt_core.hpp: mesh_closest_reference_order)
+            if (ti != 0xffffffffu && dd == best.d && (ti != best.tri || leaf_tie)) best.tie = true;
             if (ti != 0xffffffffu && (dd < best.d || (dd == best.d && ti < best.tri))) {
+                if (dd < best.d) best.tie = leaf_tie;
                 best.d = dd;
                 best.tri = ti;
                 best.ref = ti;
@@ -664,6 +680,10 @@ __device__ __forceinline__ int32_t cast_ray(const SceneView &sv, Park park, Stac
         TriBest tb;
         mesh_closest<COUNT>(sv, m, lo, ld, qs, q, t_stop, tb, cnt);
         if (!tb.hit) continue;
+        if (tb.tie && !any_hit) {  // (a shadow query only consumes the distance)
+            redo = true;
+            continue;
+        }
         V3 p;
         double u, v, w;
         tri_point(sv.tris[m.tri_base + tb.tri], lo, ld, p, u, v, w);
