@@ -259,7 +259,7 @@ typedef struct {
     float level_ms_shade[RTHIP_MAX_RECURSION + 1];
     float level_ms_easy[RTHIP_MAX_RECURSION + 1];
     float ms_easy;               /* summed duration of k_trace_easy */
-    uint32_t pad2;
+    uint32_t rays_redo;          /* rays (all levels, last chunk) re-traced through the reference kd-tree: kd-degenerate rays and exact distance ties */
     uint64_t rays_hard;          /* rays (all levels) that needed a mesh walk = rays traced by the dominant kernel */
     uint64_t shape_tests_easy;   /* RTHIP_COUNTERS=1: shape-table entries tested by k_trace_easy (shape_tests: by the dominant kernel) */
 } rthip_stats;

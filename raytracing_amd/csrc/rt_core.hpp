@@ -379,7 +379,17 @@ struct TriBest {
     uint32_t ref;  // position in the pre-order leaf-reference array (kd walk) / the triangle index (BVH walk)
     bool hit;
     bool tie;      // another triangle was accepted at exactly the distance `d` (see mesh_closest_reference_order)
+    double ext;    // largest bounding-box edge of the triangles accepted at exactly `d` (bounds where their kd leaves can be)
 };
+// largest edge of the triangle's bounding box, from its cached edges (vertices v0, v0 + e0, v0 + e1)
+RT_HD double tri_extent(const rthip_tri &t) {
+    double m = 0.0;
+    for (int a = 0; a < 3; a++) {
+        const double lo = fmin(0.0, fmin(t.e0[a], t.e1[a])), hi = fmax(0.0, fmax(t.e0[a], t.e1[a]));
+        m = fmax(m, hi - lo);
+    }
+    return m;
+}
 
 // Scene.cpp:421-467 IntersectTriangle + :495-507 Baricentric: plane projection, back-face /
 // behind-plane cull, inclusive barycentric test.  Updates `best` with the strict '<' of Scene.cpp:479.
@@ -407,9 +417,15 @@ RT_HD void tri_test(const rthip_tri &t, V3 o, V3 d, uint32_t tri, uint32_t ref, 
     double u = 1.0 - v - w;
     if (u >= 0 && v >= 0 && w >= 0) {
         double dd = sqlen(sub(o, projection));
-        if (best.hit && dd == best.d && tri != best.tri) best.tie = true;
+        if (best.hit && dd == best.d && tri != best.tri) {
+            best.tie = true;
+            best.ext = fmax(best.ext, tri_extent(t));
+        }
         if (dd < best.d || (best.hit && dd == best.d && ref < best.ref)) {
-            if (dd < best.d) best.tie = false;
+            if (dd < best.d) {
+                best.tie = false;
+                best.ext = tri_extent(t);
+            }
             best.d = dd;
             best.tri = tri;
             best.ref = ref;
@@ -439,9 +455,15 @@ RT_HD void tri_test_bvh(const rthip_tri &t, V3 o, V3 d, const uint32_t *index, u
         double dd = sqlen(sub(o, projection));
         if (dd <= best.d) {
             uint32_t ti = index[pos];
-            if (best.hit && dd == best.d && ti != best.tri) best.tie = true;
+            if (best.hit && dd == best.d && ti != best.tri) {
+                best.tie = true;
+                best.ext = fmax(best.ext, tri_extent(t));
+            }
             if (dd < best.d || (best.hit && ti < best.tri)) {
-                if (dd < best.d) best.tie = false;
+                if (dd < best.d) {
+                    best.tie = false;
+                    best.ext = tri_extent(t);
+                }
                 best.d = dd;
                 best.tri = ti;
                 best.ref = ti;
@@ -500,6 +522,7 @@ RT_HD void mesh_closest(const SceneView &sv, const rthip_mesh &m, V3 o, V3 d, Kd
                                  KdCounters *cnt) {
     best.hit = false;
     best.tie = false;
+    best.ext = 0.0;
     best.d = DBL_MAX;
     best.tri = 0xffffffffu;
     best.ref = 0xffffffffu;
@@ -579,12 +602,26 @@ RT_HD void mesh_closest(const SceneView &sv, const rthip_mesh &m, V3 o, V3 d, Kd
 }
 
 // Mesh::IntersectInternal as written (Scene.cpp:469-493): every node whose box passes BoundingBox::Intersect, Left
-// subtree before Right, the triangles of a leaf in reference order, strict '<' - no reordering, no pruning.  Only
-// queries whose fast walk ended in an exact tie come here (a handful of rays per frame at most), so that the
-// triangle returned is the one the reference returns (its id, and with vertex normals its normal).
-RT_HD void mesh_closest_reference_order(const SceneView &sv, const rthip_mesh &m, V3 o, V3 d, KdStack &st, TriBest &best) {
+// subtree before Right, the triangles of a leaf in reference order, strict '<' - no reordering, no distance pruning.
+// Only queries whose fast walk ended in an exact tie come here, so that the triangle returned is the one the
+// reference returns (its id, and with vertex normals its normal).
+// What IS left out: subtrees that cannot reference a tied triangle.  The fast walk has tested every triangle
+// accepted at the winning distance (its culling never skips a box that could hold a closer-or-EQUAL hit), all of
+// them contain the hit point `at` (to rounding), and `ext` is their largest bounding-box edge; the kd build only
+// hands a triangle to a child whose box its bounding box overlaps (Scene.cpp:59-70), so every leaf that
+// references one of them lies within `ext` of `at` on every axis.  Skipping the others leaves the order of the
+// leaves that matter untouched - and keeps a ray that runs along a grid line of a 300 K-triangle height field
+// (a tie at every crossing) from testing every triangle on its way: 40 ms for one lane.
+// `tied` / `n_tied`: the triangles accepted at exactly the winning distance `dist`, when the caller knows them
+// (tied_triangles below): the leaves are then only SCANNED for the first reference to one of them (4 bytes per
+// reference instead of a 128-byte record and an fp64 test - the reference's tree keeps leaves of thousands of
+// triangles where its 50 % rule stops a split, and one lane testing 10 000 of them in turn takes 15 ms).
+// n_tied = 0: every triangle of every visited leaf is tested, as the reference does.
+RT_HD void mesh_closest_reference_order(const SceneView &sv, const rthip_mesh &m, V3 o, V3 d, KdStack &st, TriBest &best, V3 at,
+                                        double ext, double dist, const uint32_t *tied, uint32_t n_tied, KdCounters *cnt) {
     best.hit = false;
     best.tie = false;
+    best.ext = 0.0;
     best.d = DBL_MAX;
     best.tri = 0xffffffffu;
     best.ref = 0xffffffffu;
@@ -593,6 +630,11 @@ RT_HD void mesh_closest_reference_order(const SceneView &sv, const rthip_mesh &m
     const double *bounds = sv.kd_bounds + 6 * (size_t)m.node_base;
     const uint32_t *refs = sv.kd_refs + m.ref_base;
     const rthip_tri *tris = sv.tris + m.tri_base;
+    const double reach = ext * (1.0 + 1e-9) + 1e-9 * (fabs(at.x) + fabs(at.y) + fabs(at.z) + ext) + 1e-300;
+    const double qlo[3] = {at.x - reach, at.y - reach, at.z - reach}, qhi[3] = {at.x + reach, at.y + reach, at.z + reach};
+    auto near_hit_point = [&](const double *b) {  // b = Min xyz, Max xyz
+        return b[0] <= qhi[0] && b[3] >= qlo[0] && b[1] <= qhi[1] && b[4] >= qlo[1] && b[2] <= qhi[2] && b[5] >= qlo[2];
+    };
     double t[6], t7;
     slab_params(bounds, o, d, t);
     if (!slab_hit(t, t7)) return;
@@ -600,28 +642,56 @@ RT_HD void mesh_closest_reference_order(const SceneView &sv, const rthip_mesh &m
     uint32_t cur = 0;
     for (;;) {
         const rthip_kdnode nd = nodes[cur];
+        if (cnt) cnt->nodes++;
         bool descend = false;
         if (nd.info & RTHIP_KD_LEAF) {
             const uint32_t count = nd.info >> RTHIP_KD_COUNT_SHIFT;
-            for (uint32_t i = 0; i < count; i++) {
-                const uint32_t ti = refs[nd.link + i];
-                TriBest one;
-                one.hit = false;
-                one.tie = false;
-                one.d = DBL_MAX;
-                one.tri = one.ref = 0xffffffffu;
-                tri_test(tris[ti], o, d, ti, nd.link + i, one);
-                if (one.hit && one.d < best.d) best = one;  // Scene.cpp:479
+            if (cnt) {
+                cnt->leaves++;
+                if (n_tied == 0) cnt->tris += count;
+            }
+            if (n_tied) {  // the first reference to a tied triangle is the first triangle to reach the winning distance
+                for (uint32_t i0 = 0; i0 < count; i0 += 8) {  // eight loads in flight: the scan is one lane's latency chain
+                    uint32_t r8[8];
+#pragma unroll
+                    for (uint32_t j = 0; j < 8; j++) r8[j] = refs[nd.link + (i0 + j < count ? i0 + j : count - 1u)];
+#pragma unroll
+                    for (uint32_t j = 0; j < 8; j++) {
+                        bool member = false;
+                        for (uint32_t k = 0; k < n_tied; k++) member = member || tied[k] == r8[j];
+                        if (member && i0 + j < count) {
+                            best.hit = true;
+                            best.d = dist;
+                            best.tri = r8[j];
+                            best.ref = nd.link + i0 + j;
+                            return;
+                        }
+                    }
+                }
+            } else {
+                for (uint32_t i = 0; i < count; i++) {
+                    const uint32_t ti = refs[nd.link + i];
+                    TriBest one;
+                    one.hit = false;
+                    one.tie = false;
+                    one.ext = 0.0;
+                    one.d = DBL_MAX;
+                    one.tri = one.ref = 0xffffffffu;
+                    tri_test(tris[ti], o, d, ti, nd.link + i, one);
+                    if (one.hit && one.d < best.d) best = one;  // Scene.cpp:479
+                }
             }
         } else {
             bool hl = false, hr = false;
             if (nd.info & RTHIP_KD_HAS_LEFT) {
-                slab_params(bounds + 6 * (size_t)(cur + 1), o, d, t);
-                hl = slab_hit(t, t7);
+                const double *b = bounds + 6 * (size_t)(cur + 1);
+                slab_params(b, o, d, t);
+                hl = slab_hit(t, t7) && near_hit_point(b);
             }
             if (nd.info & RTHIP_KD_HAS_RIGHT) {
-                slab_params(bounds + 6 * (size_t)nd.link, o, d, t);
-                hr = slab_hit(t, t7);
+                const double *b = bounds + 6 * (size_t)nd.link;
+                slab_params(b, o, d, t);
+                hr = slab_hit(t, t7) && near_hit_point(b);
             }
             if (hl) {
                 if (hr) st.push(nd.link);
@@ -711,6 +781,7 @@ RT_HD void mesh_closest_bvh(const SceneView &sv, const rthip_mesh &m, V3 o, V3 d
                             float t_stop, KdCounters *cnt) {
     best.hit = false;
     best.tie = false;
+    best.ext = 0.0;
     best.d = DBL_MAX;
     best.tri = 0xffffffffu;
     best.ref = 0xffffffffu;
@@ -776,6 +847,51 @@ RT_HD void mesh_closest_bvh(const SceneView &sv, const rthip_mesh &m, V3 o, V3 d
     }
 }
 
+// The triangles of the mesh accepted at exactly squared distance `dist` (the winning one: nothing is closer), through
+// the BVH with the search bounded at that distance from the start: a handful of boxes around the hit point.
+// Returns their number, kMaxTied + 1 when there are more than `tied` holds.
+static const uint32_t kMaxTied = 8;
+RT_HD uint32_t tied_triangles(const SceneView &sv, const rthip_mesh &m, V3 o, V3 d, KdStack &st, double dist, uint32_t *tied) {
+    const rthip_bvhnode *nodes = sv.bvh_nodes + m.bvh_node_base;
+    const rthip_tri *tris = sv.bvh_tris + m.bvh_tri_base;
+    const uint32_t *index = sv.bvh_tri_index + m.bvh_tri_base;
+    const BvhRay r = bvh_ray(o, d, m.abs_max);
+    const float tmax = bvh_tmax_of(dist);
+    uint32_t n = 0;
+    st.clear();
+    uint32_t cur = 0;
+    for (;;) {
+        if (!(cur & RTHIP_BVH_LEAF)) {
+            const rthip_bvhnode &nd = nodes[cur];
+            for (int c = 0; c < 4; c++) {
+                float tn;
+                bool h;
+                bvh_slab(nd.c[c].lo, nd.c[c].hi, r, tmax, tn, h);
+                if (h && nd.c[c].child != RTHIP_BVH_ABSENT) st.push_t(nd.c[c].child, tn);
+            }
+        } else {
+            const uint32_t first = cur & RTHIP_BVH_FIRST_MASK, count = ((cur >> RTHIP_BVH_COUNT_SHIFT) & 7u) + 1u;
+            for (uint32_t i = 0; i < count; i++) {
+                TriBest one;
+                one.hit = false;
+                one.tie = false;
+                one.ext = 0.0;
+                one.d = DBL_MAX;
+                one.tri = one.ref = 0xffffffffu;
+                tri_test(tris[first + i], o, d, 0u, 0u, one);
+                if (one.hit && one.d == dist) {
+                    if (n == kMaxTied) return kMaxTied + 1u;
+                    tied[n++] = index[first + i];
+                }
+            }
+        }
+        if (st.empty()) break;
+        float t;
+        cur = st.pop_t(t);
+    }
+    return n;
+}
+
 // true iff `v` is exactly one of the mesh's kd box-plane coordinates on `axis` (binary search)
 RT_HD bool kd_on_plane(const SceneView &sv, const rthip_mesh &m, uint32_t axis, double v) {
     const double *p = sv.kd_planes + m.plane_base[axis];
@@ -824,7 +940,18 @@ RT_HD bool shape_intersect(const SceneView &sv, int32_t type, int32_t mesh, V3 p
         mesh_closest(sv, m, lo, ld, st, tb, cnt);
     // an exact tie at the winning distance: which triangle wins is the reference walk's business (a shadow query
     // only consumes the distance: t_stop < 3e38 marks it)
-    if (tb.hit && tb.tie && !(t_stop < 3.0e38f)) mesh_closest_reference_order(sv, m, lo, ld, st, tb);
+    if (tb.hit && tb.tie && !(t_stop < 3.0e38f)) {
+        V3 at;
+        double u, v, w;
+        tri_point(sv.tris[m.tri_base + tb.tri], lo, ld, at, u, v, w);
+        const double dist = tb.d, ext = tb.ext;
+        uint32_t tied[kMaxTied], n_tied = 0;
+        if (m.bvh_node_count) {
+            n_tied = tied_triangles(sv, m, lo, ld, st, dist, tied);
+            if (n_tied > kMaxTied) n_tied = 0;  // (a fan of more than eight: test everything, like the reference)
+        }
+        mesh_closest_reference_order(sv, m, lo, ld, st, tb, at, ext, dist, tied, n_tied, cnt);
+    }
     if (!tb.hit) return false;
     tri = (int32_t)tb.tri;
     double u, v, w;

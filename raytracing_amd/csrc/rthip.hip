@@ -487,6 +487,7 @@ __device__ __forceinline__ void mesh_closest(const SceneView &sv, const rthip_me
                                              float t_stop, TriBest &best, KdCounters &cnt) {
     best.hit = false;
     best.tie = false;
+    best.ext = 0.0;
     best.d = DBL_MAX;
     best.tri = 0xffffffffu;
     best.ref = 0xffffffffu;
@@ -2158,6 +2159,9 @@ static int finish_stats(rthip_ctx *c, const rthip_params *p) {
         for (uint32_t i = 0; i <= p->max_recursion && i <= RTHIP_MAX_RECURSION; i++) hard += all[(size_t)(2 * (RTHIP_MAX_RECURSION + 3) + i) * kCounterStride];
         for (uint32_t i = 0; i <= RTHIP_MAX_RECURSION; i++) c->last.level_rays[i] = i <= p->max_recursion ? all[(size_t)i * kCounterStride] : 0;
         c->last.rays_hard = p->accel == 0 ? hard : 0;  // last chunk only (frames of <= 2^24 rays per level are one chunk)
+        uint64_t redo = 0;
+        for (uint32_t i = 0; i <= p->max_recursion && i <= RTHIP_MAX_RECURSION; i++) redo += all[(size_t)((RTHIP_MAX_RECURSION + 3) + i) * kCounterStride];
+        c->last.rays_redo = p->accel == 0 ? (uint32_t)std::min<uint64_t>(redo, 0xffffffffu) : 0;
     }
     memset(c->last.level_ms_trace, 0, sizeof c->last.level_ms_trace);
     memset(c->last.level_ms_shade, 0, sizeof c->last.level_ms_shade);

@@ -46,7 +46,7 @@ class Stats(C.Structure):
                 ("wave_steps_max", C.c_uint64), ("wave_tris_max", C.c_uint64), ("wave_steps", C.c_uint64), ("wave_tris", C.c_uint64),
                 ("wave_cycles_max", C.c_uint64), ("fetch_cycles", C.c_uint64),
                 ("level_rays", C.c_uint32 * 17), ("level_ms_trace", C.c_float * 17), ("level_ms_shade", C.c_float * 17), ("level_ms_easy", C.c_float * 17),
-                ("ms_easy", C.c_float), ("pad2", C.c_uint32), ("rays_hard", C.c_uint64), ("shape_tests_easy", C.c_uint64)]
+                ("ms_easy", C.c_float), ("rays_redo", C.c_uint32), ("rays_hard", C.c_uint64), ("shape_tests_easy", C.c_uint64)]
 
 
 class Mesh(C.Structure):  # rthip_mesh
