@@ -266,6 +266,55 @@ __device__ __forceinline__ Box box_of(uint32_t ref, const Box *node_box, const B
 // number of triangles under a reference
 __device__ __forceinline__ uint32_t span_of(uint32_t ref, const PNode *nodes) { return (ref & 0x80000000u) ? 1u : nodes[ref].size; }
 
+// The optimal collapse of the binary tree to 4-wide nodes under the surface-area cost (the host builder's, mesh_build.hpp;
+// Ylitie, Karras, Laine 2017, section 3.1): c[i-1] = cheapest way to stand for the subtree as at most i wide sub-trees.
+// A greedy "open the largest child, a subtree of <= 4 triangles is a leaf" collapse left 3.07 children per node and one
+// more level than the host tree at the bottom of a 2 M-triangle height field.
+struct Plan {
+    float c[3];
+    uint8_t k[3];  // k[0]: slots of an interior node's four that the left child takes; k[i-1], i = 2, 3: left share of the forest, 0 = no better than i - 1
+    uint8_t leaf;  // as ONE tree the subtree is a leaf (<= 4 triangles)
+};
+static const float kLeafCost = 1.5f;  // a triangle step (<= 4 fp64 tests) against a node step (4 fp32 slab tests)
+__device__ __forceinline__ float cost_of(uint32_t ref, int i, const Plan *plan, const Box *prim_box, const uint32_t *index) {
+    return (ref & 0x80000000u) ? area(prim_box[index[ref & 0x7fffffffu]]) * kLeafCost : plan[ref].c[i - 1];
+}
+// binary nodes [first, last): their children were made by earlier clustering passes, so their plans are ready
+__global__ __launch_bounds__(kB) void k_plan(uint32_t first, uint32_t last, const PNode *bin, const Box *node_box, const Box *prim_box, const uint32_t *index,
+                                             Plan *plan) {
+    const uint32_t id = first + blockIdx.x * kB + threadIdx.x;
+    if (id >= last) return;
+    const PNode nd = bin[id];
+    const float a_me = area(node_box[id]);
+    float dist[5];
+    uint8_t at[5];
+    for (int j = 2; j <= 4; j++) {
+        dist[j] = 3.0e38f;
+        at[j] = 1;
+        for (int k = 1; k < j; k++) {
+            const float c = cost_of(nd.left, k < 3 ? k : 3, plan, prim_box, index) + cost_of(nd.right, j - k < 3 ? j - k : 3, plan, prim_box, index);
+            if (c < dist[j]) { dist[j] = c; at[j] = (uint8_t)k; }
+        }
+    }
+    Plan p;
+    const float interior = dist[4] + a_me, as_leaf = nd.size <= RTHIP_BVH_MAX_LEAF ? a_me * kLeafCost : 3.0e38f;
+    p.leaf = as_leaf <= interior;
+    p.c[0] = p.leaf ? as_leaf : interior;
+    p.k[0] = at[4];
+    for (int i = 2; i <= 3; i++) {
+        const bool better = dist[i] < p.c[i - 2];
+        p.c[i - 1] = better ? dist[i] : p.c[i - 2];
+        p.k[i - 1] = better ? at[i] : 0;
+    }
+    plan[id] = p;
+}
+__global__ __launch_bounds__(kB) void k_count_interior(const Plan *plan, uint32_t n_internal, uint32_t *count) {
+    const uint32_t i = blockIdx.x * kB + threadIdx.x;
+    const bool big = i < n_internal && !plan[i].leaf;
+    const unsigned long long m = __ballot(big);
+    if ((threadIdx.x & 63u) == 0 && m) atomicAdd(count, (uint32_t)__popcll(m));
+}
+
 struct Item {
     uint32_t bin_node;   // binary node this wide node is made from (covers > 4 triangles)
     uint32_t wide_node;  // its index in the output
@@ -275,34 +324,42 @@ struct Item {
 // Breadth-first collapse, one launch per level.  Leaf order is assigned on the way down: a node's triangles take the positions
 // [first, first + size), its children one after the other, so that a leaf's triangles are contiguous (leaf word = first, count).
 __global__ __launch_bounds__(kB) void k_collapse(const Item *items, uint32_t n_items, const PNode *bin, const Box *node_box, const Box *prim_box,
-                                                 const uint32_t *index, rthip_bvhnode *out, uint32_t out_cap, uint32_t *counters /* [0] nodes, [1] next items, [2] overflow */,
-                                                 Item *next, uint32_t *leaf_index) {
+                                                 const uint32_t *index, const Plan *plan, rthip_bvhnode *out, uint32_t out_cap,
+                                                 uint32_t *counters /* [0] nodes, [1] next items, [2] overflow */, Item *next, uint32_t *leaf_index) {
     const uint32_t t = blockIdx.x * kB + threadIdx.x;
     if (t >= n_items) return;
     const Item it = items[t];
     uint32_t ref[4];
     Box box[4];
-    const PNode root = bin[it.bin_node];
-    ref[0] = root.left;
-    ref[1] = root.right;
-    box[0] = box_of(ref[0], node_box, prim_box, index);
-    box[1] = box_of(ref[1], node_box, prim_box, index);
-    int cnt = 2;
-    while (cnt < 4) {  // open the child with the largest box that is still a subtree of more than four triangles
-        int pick = -1;
-        float best = -1.0f;
-        for (int k = 0; k < cnt; k++) {
-            if (span_of(ref[k], bin) <= RTHIP_BVH_MAX_LEAF) continue;
-            const float a = area(box[k]);
-            if (a > best) { best = a; pick = k; }
+    int cnt = 0;
+    {   // the planned children, left to right: the roots of the forests of the two binary children
+        const PNode root = bin[it.bin_node];
+        const uint32_t k0 = plan[it.bin_node].k[0];
+        uint32_t st_ref[4], st_i[4];
+        int sp = 0;
+        st_ref[sp] = root.right; st_i[sp++] = 4u - k0;
+        st_ref[sp] = root.left; st_i[sp++] = k0;
+        while (sp && cnt < 4) {
+            const uint32_t r = st_ref[--sp];
+            uint32_t i = st_i[sp];
+            bool open = false;
+            if (!(r & 0x80000000u)) {
+                const Plan p = plan[r];
+                if (i > 3u) i = 3u;
+                while (i > 1u && p.k[i - 1u] == 0) i--;
+                if (i > 1u && sp + 2 <= 4) {
+                    const PNode o = bin[r];
+                    st_ref[sp] = o.right; st_i[sp++] = i - p.k[i - 1u];
+                    st_ref[sp] = o.left; st_i[sp++] = p.k[i - 1u];
+                    open = true;
+                }
+            }
+            if (!open) {
+                ref[cnt] = r;
+                box[cnt] = box_of(r, node_box, prim_box, index);
+                cnt++;
+            }
         }
-        if (pick < 0) break;
-        const PNode o = bin[ref[pick]];
-        ref[pick] = o.left;
-        box[pick] = box_of(o.left, node_box, prim_box, index);
-        ref[cnt] = o.right;
-        box[cnt] = box_of(o.right, node_box, prim_box, index);
-        cnt++;
     }
     rthip_bvhnode nd;
     uint32_t first = it.first;
@@ -316,7 +373,7 @@ __global__ __launch_bounds__(kB) void k_collapse(const Item *items, uint32_t n_i
         for (int a = 0; a < 3; a++) { nd.c[k].lo[a] = box[k].lo[a]; nd.c[k].hi[a] = box[k].hi[a]; }
         nd.c[k].pad = 0;
         const uint32_t span = span_of(ref[k], bin);
-        if (span <= RTHIP_BVH_MAX_LEAF) {
+        if ((ref[k] & 0x80000000u) || plan[ref[k]].leaf) {
             nd.c[k].child = RTHIP_BVH_LEAF | ((span - 1u) << RTHIP_BVH_COUNT_SHIFT) | first;
             uint32_t stack[RTHIP_BVH_MAX_LEAF], sp = 0, w = first;  // the (at most four) triangles of the subtree, left to right
             stack[sp++] = ref[k];
@@ -363,13 +420,6 @@ __global__ void k_tiny(const Box *prim_box, uint32_t n, rthip_bvhnode *out) {
         nd.c[k].pad = 0;
     }
     out[0] = nd;
-}
-
-__global__ __launch_bounds__(kB) void k_count_big(const PNode *bin, uint32_t n_internal, uint32_t *count) {
-    const uint32_t i = blockIdx.x * kB + threadIdx.x;
-    const bool big = i < n_internal && bin[i].size > RTHIP_BVH_MAX_LEAF;
-    const unsigned long long m = __ballot(big);
-    if ((threadIdx.x & 63u) == 0 && m) atomicAdd(count, (uint32_t)__popcll(m));
 }
 
 // bvh_tris[k] = tris[bvh_index[k]]
@@ -474,6 +524,7 @@ static int build_nodes(hipStream_t stream, const rthip_tri *d_tris, uint32_t n, 
     // (Passes that first form leaves of at most four triangles - leaf_limit = 4 - fill the leaves better, 3.6 instead of 3.1
     // triangles, but the greedy groups have worse boxes: 4 % more traversal steps and 8 % slower frames on config 4.  Off.)
     uint32_t leaf_limit = 0;
+    std::vector<uint32_t> made;  // binary nodes in existence after every clustering pass
     for (int pass = 0; nc > 1; pass++) {
         if (pass > 4096) {
             snprintf(err, err_len, "BVH build: clustering did not converge (%u clusters left)", nc);
@@ -486,9 +537,11 @@ static int build_nodes(hipStream_t stream, const rthip_tri *d_tris, uint32_t n, 
         BHIP(rocprim::exclusive_scan(scan_tmp.p, scan_bytes, valid.as<uint32_t>(), pos.as<uint32_t>(), 0u, (size_t)nc, rocprim::plus<uint32_t>(), stream));
         hipLaunchKernelGGL(k_ploc_compact, dim3(g), dim3(kB), 0, stream, valid.as<uint32_t>(), pos.as<uint32_t>(), boxB.as<Box>(), refB.as<uint32_t>(), sizeB.as<uint32_t>(), nc,
                            boxA.as<Box>(), refA.as<uint32_t>(), sizeA.as<uint32_t>(), cnt + 5);
-        uint32_t left = 0;
+        uint32_t left = 0, made_now = 0;
         BHIP(hipMemcpyAsync(&left, cnt + 5, sizeof left, hipMemcpyDeviceToHost, stream));
+        BHIP(hipMemcpyAsync(&made_now, cnt + 4, sizeof made_now, hipMemcpyDeviceToHost, stream));
         BHIP(hipStreamSynchronize(stream));
+        made.push_back(made_now);
         if (leaf_limit && left == nc) {  // no pair of at most four triangles left: on to the tree above the leaves
             leaf_limit = 0;
             continue;
@@ -506,8 +559,24 @@ static int build_nodes(hipStream_t stream, const rthip_tri *d_tris, uint32_t n, 
         snprintf(err, err_len, "BVH build: the clustering left a triangle as the root");
         return RTHIP_E_HIP;
     }
-    // upper bound of the wide nodes: every wide node is made from a different binary node of more than four triangles
-    hipLaunchKernelGGL(k_count_big, dim3((n_int + kB - 1) / kB), dim3(kB), 0, stream, bin.as<PNode>(), n_int, cnt + 3);
+    // the collapse plan, bottom-up in the order the clustering made the nodes (a pass only merges clusters of earlier passes)
+    Tmp plan;
+    BHIP(plan.alloc(sizeof(Plan) * (size_t)n_int));
+    {
+        uint32_t from = 0;
+        for (uint32_t upto : made) {
+            if (upto > from)
+                hipLaunchKernelGGL(k_plan, dim3((upto - from + kB - 1) / kB), dim3(kB), 0, stream, from, upto, bin.as<PNode>(), node_box.as<Box>(), prim_box.as<Box>(),
+                                   index, plan.as<Plan>());
+            from = upto;
+        }
+        if (from != n_int) {
+            snprintf(err, err_len, "BVH build: %u binary nodes made, %u expected", from, n_int);
+            return RTHIP_E_HIP;
+        }
+    }
+    // upper bound of the wide nodes: every wide node is made from a different binary node that is not planned as a leaf
+    hipLaunchKernelGGL(k_count_interior, dim3((n_int + kB - 1) / kB), dim3(kB), 0, stream, plan.as<Plan>(), n_int, cnt + 3);
     uint32_t cap = 0;
     BHIP(hipMemcpyAsync(&cap, cnt + 3, sizeof cap, hipMemcpyDeviceToHost, stream));
     BHIP(hipStreamSynchronize(stream));
@@ -526,7 +595,7 @@ static int build_nodes(hipStream_t stream, const rthip_tri *d_tris, uint32_t n, 
     Item *cur = items_a.as<Item>(), *nxt = items_b.as<Item>();
     for (;;) {
         hipLaunchKernelGGL(k_collapse, dim3((n_items + kB - 1) / kB), dim3(kB), 0, stream, cur, n_items, bin.as<PNode>(), node_box.as<Box>(), prim_box.as<Box>(), index,
-                           nodes, cap, cnt, nxt, d_bvh_index);
+                           plan.as<Plan>(), nodes, cap, cnt, nxt, d_bvh_index);
         uint32_t c3[3];
         BHIP(hipMemcpyAsync(c3, cnt, sizeof c3, hipMemcpyDeviceToHost, stream));
         BHIP(hipStreamSynchronize(stream));
