@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""Per-level kernel times (RTHIP_PROFILE_LAUNCHES=1), re-traced ray count and, with RTHIP_COUNTERS=1, traversal counters of the
+interrupt test's frame (config 4 height field of `cells` x `cells`, 4096 x 4096, MaxRecursion 16).  usage: gpu_irq_probe2.py [cells]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["RTHIP_PROFILE_LAUNCHES"] = "1"
