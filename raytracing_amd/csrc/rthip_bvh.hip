@@ -8,15 +8,17 @@
 // Input: the mesh's triangle records already in HBM (rthip_tri, mesh order).  Pipeline, all on one stream:
 //   k_prims     : per triangle the fp32 box (rounded OUTWARD like the host builder's Down / Up) and the centroid; bounds of
 //                 the centroids and max |coordinate| by wave reduction + atomics on order-preserving integer keys
-//   k_morton    : 63-bit Morton code of the centroid (21 bits per axis)
-//   rocprim     : radix sort of (code, triangle index)
-//   k_ploc_*    : binary tree by parallel locally-ordered clustering (Meister & Bittner 2018): every cluster looks 16 places
-//                 to either side in Morton order for the neighbour with the smallest union box, mutual nearest neighbours
-//                 merge, the array is compacted (rocprim scan), repeat until one cluster is left (a few dozen passes)
-//   k_collapse  : breadth-first, one launch per level: a wide node takes a binary node, opens the child with the largest box
-//                 until it has four children; a subtree of <= 4 triangles becomes a leaf (one triangle per lane of the quad
-//                 that walks it); leaf order is assigned on the way down; node indices grow with depth (children follow
-//                 their parent, as the host builder's)
+//   binary tree : (default) k_sah_*: top-down binned SAH, the host builder's algorithm (16 bins per axis over the centroid
+//                 bounds, cost = area x ceil(count / 4) per side, down to single triangles) - level-synchronous for nodes of
+//                 more than 64 triangles (bounds, bins, split, partition: one launch each per level, LDS accumulation for
+//                 the chunks that lie inside one node), one wave per subtree of <= 64 triangles (full sweep, a lane per
+//                 triangle); every link of the result is checked (k_sah_validate) before anything walks it.
+//                 (RTHIP_BVH_BUILDER=ploc) k_morton + rocprim radix sort + k_ploc_*: parallel locally-ordered clustering
+//                 (Meister & Bittner 2018) in Morton order - 1.7x faster to build, 22 % slower to walk on config 4
+//   k_plan      : the optimal collapse of the binary tree to 4-wide nodes and leaves of <= 4 triangles under the surface-area
+//                 cost (bottom-up: by clustering pass / by depth)
+//   k_collapse  : breadth-first, one launch per level, children as planned; leaf order is assigned on the way down; node
+//                 indices grow with depth (children follow their parent, as the host builder's)
 //   k_gather    : triangle records in leaf order
 // Output layout = include/rthip.h (rthip_bvhnode, 128 B; leaf words; RTHIP_BVH_ABSENT).
 #include <hip/hip_runtime.h>
@@ -104,6 +106,7 @@ __global__ __launch_bounds__(kB) void k_prims(const rthip_tri *tris, uint32_t n,
             b.lo[k] = round_down(l);
             b.hi[k] = round_up(h);
             c[k] = (float)(0.5 * (l + h));
+            if (!(fabsf(c[k]) < 3.0e38f)) c[k] = 0.0f;  // (the builders order triangles by centroid: keep it comparable)
             am = fmaxf(am, fmaxf(fabsf(b.lo[k]), fabsf(b.hi[k])));
         }
         prim_box[i] = b;
@@ -279,11 +282,7 @@ static const float kLeafCost = 1.5f;  // a triangle step (<= 4 fp64 tests) again
 __device__ __forceinline__ float cost_of(uint32_t ref, int i, const Plan *plan, const Box *prim_box, const uint32_t *index) {
     return (ref & 0x80000000u) ? area(prim_box[index[ref & 0x7fffffffu]]) * kLeafCost : plan[ref].c[i - 1];
 }
-// binary nodes [first, last): their children were made by earlier clustering passes, so their plans are ready
-__global__ __launch_bounds__(kB) void k_plan(uint32_t first, uint32_t last, const PNode *bin, const Box *node_box, const Box *prim_box, const uint32_t *index,
-                                             Plan *plan) {
-    const uint32_t id = first + blockIdx.x * kB + threadIdx.x;
-    if (id >= last) return;
+__device__ __forceinline__ void plan_node(uint32_t id, const PNode *bin, const Box *node_box, const Box *prim_box, const uint32_t *index, Plan *plan) {
     const PNode nd = bin[id];
     const float a_me = area(node_box[id]);
     float dist[5];
@@ -298,7 +297,7 @@ __global__ __launch_bounds__(kB) void k_plan(uint32_t first, uint32_t last, cons
     }
     Plan p;
     const float interior = dist[4] + a_me, as_leaf = nd.size <= RTHIP_BVH_MAX_LEAF ? a_me * kLeafCost : 3.0e38f;
-    p.leaf = as_leaf <= interior;
+    p.leaf = nd.size <= RTHIP_BVH_MAX_LEAF && as_leaf <= interior;  // (never a leaf of more than four, whatever the costs)
     p.c[0] = p.leaf ? as_leaf : interior;
     p.k[0] = at[4];
     for (int i = 2; i <= 3; i++) {
@@ -307,6 +306,20 @@ __global__ __launch_bounds__(kB) void k_plan(uint32_t first, uint32_t last, cons
         p.k[i - 1] = better ? at[i] : 0;
     }
     plan[id] = p;
+}
+// binary nodes [first, last): their children were made by earlier clustering passes, so their plans are ready
+__global__ __launch_bounds__(kB) void k_plan(uint32_t first, uint32_t last, const PNode *bin, const Box *node_box, const Box *prim_box, const uint32_t *index,
+                                             Plan *plan) {
+    const uint32_t id = first + blockIdx.x * kB + threadIdx.x;
+    if (id >= last) return;
+    plan_node(id, bin, node_box, prim_box, index, plan);
+}
+// the binary nodes at depth d of a tree built top-down (deepest first: the children's plans are ready)
+__global__ __launch_bounds__(kB) void k_plan_depth(uint32_t n_nodes, uint32_t d, const uint32_t *node_depth, const PNode *bin, const Box *node_box,
+                                                   const Box *prim_box, const uint32_t *index, Plan *plan) {
+    const uint32_t id = blockIdx.x * kB + threadIdx.x;
+    if (id >= n_nodes || node_depth[id] != d) return;
+    plan_node(id, bin, node_box, prim_box, index, plan);
 }
 __global__ __launch_bounds__(kB) void k_count_interior(const Plan *plan, uint32_t n_internal, uint32_t *count) {
     const uint32_t i = blockIdx.x * kB + threadIdx.x;
@@ -432,6 +445,416 @@ __global__ __launch_bounds__(kB) void k_gather(const rthip_tri *tris, const uint
     reinterpret_cast<uint4 *>(bvh_tris + rec)[part] = reinterpret_cast<const uint4 *>(tris + src)[part];
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Binary tree by top-down binned SAH on the device - the host builder's algorithm (mesh_build.hpp: 16 bins on each axis over
+// the centroid bounds, cost = area * ceil(count / 4) per side, down to single triangles), level-synchronous for the nodes of
+// more than kSmall triangles (bounds -> bins -> split -> partition, one launch each per level; a 2048-position chunk that lies
+// inside one node accumulates in LDS and flushes once) and one WAVE per subtree of <= kSmall triangles (one triangle per lane,
+// every lane's centroid a candidate plane on each axis: a full sweep).  Positions: `order` holds triangle ids, a node owns a
+// contiguous range; a leaf reference is 0x80000000 | position, as in the clustering builder.
+const uint32_t kSmall = 64, kChunk = 2048, kNone = 0xffffffffu, kSahBins = 16;
+const uint32_t kNbWords = 12, kBinWords = 3 * kSahBins * 7;
+struct ANode { uint32_t lo, hi, parent, side; };                   // parent: binary node whose child link this node fills in (kNone: the root)
+struct Job { uint32_t lo, hi, parent, side, depth, pad[3]; };
+struct SplitRec { int32_t axis; uint32_t bin, mid, slot[2]; };     // axis < 0: split by position; slot: next level's node of each side, kNone if finished
+enum { SC_NODES = 0, SC_NEXT = 1, SC_JOBS = 2, SC_ROOT = 3, SC_DEPTH = 4 };
+
+__global__ __launch_bounds__(kB) void k_sah_clear(uint32_t *nb, uint32_t *bins, uint32_t n_active) {
+    const uint32_t i = blockIdx.x * kB + threadIdx.x;
+    if (i < n_active * kNbWords) {
+        const uint32_t w = i % kNbWords;
+        nb[i] = (w < 3 || (w >= 6 && w < 9)) ? 0xffffffffu : 0u;
+    }
+    if (i < n_active * kBinWords) {
+        const uint32_t w = i % 7u;
+        bins[i] = w == 0 ? 0u : (w < 4 ? 0xffffffffu : 0u);
+    }
+}
+// per node: [0..2] / [3..5] min / max keys of the triangle boxes, [6..8] / [9..11] of the centroids
+__global__ __launch_bounds__(kB) void k_sah_bounds(const uint32_t *order, const uint32_t *seg, uint32_t n, const Box *prim_box, const float *centroid,
+                                                   uint32_t *nb) {
+    __shared__ uint32_t sh[kNbWords];
+    const uint32_t c0 = blockIdx.x * kChunk, c1 = min(n, c0 + kChunk);
+    const uint32_t s0 = seg[c0], s1 = seg[c1 - 1];
+    if (s0 == s1 && s0 != kNone) {  // a node's range is contiguous: the whole chunk is its (finished positions are not ONE range)
+        if (threadIdx.x < kNbWords) sh[threadIdx.x] = (threadIdx.x < 3 || (threadIdx.x >= 6 && threadIdx.x < 9)) ? 0xffffffffu : 0u;
+        __syncthreads();
+        uint32_t k[kNbWords];
+#pragma unroll
+        for (int w = 0; w < (int)kNbWords; w++) k[w] = (w < 3 || (w >= 6 && w < 9)) ? 0xffffffffu : 0u;
+        for (uint32_t p = c0 + threadIdx.x; p < c1; p += kB) {
+            const uint32_t t = order[p];
+            const Box b = prim_box[t];
+#pragma unroll
+            for (int a = 0; a < 3; a++) {
+                const uint32_t ck = f2key(centroid[3 * (size_t)t + a]);
+                k[a] = min(k[a], f2key(b.lo[a]));
+                k[3 + a] = max(k[3 + a], f2key(b.hi[a]));
+                k[6 + a] = min(k[6 + a], ck);
+                k[9 + a] = max(k[9 + a], ck);
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+            for (int w = 0; w < (int)kNbWords; w++) {
+                const uint32_t o = (uint32_t)__shfl_xor((int)k[w], off, 64);
+                k[w] = (w < 3 || (w >= 6 && w < 9)) ? min(k[w], o) : max(k[w], o);
+            }
+        }
+        if ((threadIdx.x & 63u) == 0) {
+#pragma unroll
+            for (int w = 0; w < (int)kNbWords; w++) {
+                if (w < 3 || (w >= 6 && w < 9)) atomicMin(&sh[w], k[w]);
+                else atomicMax(&sh[w], k[w]);
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < kNbWords) {
+            uint32_t *dst = nb + (size_t)s0 * kNbWords + threadIdx.x;
+            if (threadIdx.x < 3 || (threadIdx.x >= 6 && threadIdx.x < 9)) atomicMin(dst, sh[threadIdx.x]);
+            else atomicMax(dst, sh[threadIdx.x]);
+        }
+        return;
+    }
+    for (uint32_t p = c0 + threadIdx.x; p < c1; p += kB) {
+        const uint32_t a_ = seg[p];
+        if (a_ == kNone) continue;
+        const uint32_t t = order[p];
+        const Box b = prim_box[t];
+        uint32_t *dst = nb + (size_t)a_ * kNbWords;
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            const uint32_t ck = f2key(centroid[3 * (size_t)t + a]);
+            atomicMin(dst + a, f2key(b.lo[a]));
+            atomicMax(dst + 3 + a, f2key(b.hi[a]));
+            atomicMin(dst + 6 + a, ck);
+            atomicMax(dst + 9 + a, ck);
+        }
+    }
+}
+__global__ __launch_bounds__(kB) void k_iota(uint32_t *a, uint32_t n) {
+    const uint32_t i = blockIdx.x * kB + threadIdx.x;
+    if (i < n) a[i] = i;
+}
+// bin of a centroid coordinate (the same expression in k_sah_bin and k_sah_partition)
+__device__ __forceinline__ uint32_t sah_bin(float c, float base, float k) {
+    int b = (int)((c - base) * k);
+    return (uint32_t)(b < 0 ? 0 : (b >= (int)kSahBins ? (int)kSahBins - 1 : b));
+}
+__device__ __forceinline__ void sah_axis(const uint32_t *nbn, int a, float &base, float &k) {
+    const float lo = key2f(nbn[6 + a]), hi = key2f(nbn[9 + a]);
+    base = lo;
+    k = hi > lo ? (float)kSahBins / (hi - lo) : 0.0f;
+}
+// per node, axis, bin: count, min keys (3), max keys (3) of the triangle boxes whose centroid falls in the bin
+__global__ __launch_bounds__(kB) void k_sah_bin(const uint32_t *order, const uint32_t *seg, uint32_t n, const Box *prim_box, const float *centroid,
+                                                const uint32_t *nb, uint32_t *bins) {
+    __shared__ uint32_t sh[kBinWords];
+    const uint32_t c0 = blockIdx.x * kChunk, c1 = min(n, c0 + kChunk);
+    const uint32_t s0 = seg[c0], s1 = seg[c1 - 1];
+    const bool uniform = s0 == s1 && s0 != kNone;  // (see k_sah_bounds)
+    if (uniform) {
+        for (uint32_t w = threadIdx.x; w < kBinWords; w += kB) sh[w] = (w % 7u) == 0 ? 0u : ((w % 7u) < 4 ? 0xffffffffu : 0u);
+        __syncthreads();
+    }
+    for (uint32_t p = c0 + threadIdx.x; p < c1; p += kB) {
+        const uint32_t nd = seg[p];
+        if (nd == kNone) continue;
+        const uint32_t t = order[p];
+        const Box b = prim_box[t];
+        const uint32_t *nbn = nb + (size_t)nd * kNbWords;
+        uint32_t *dst = uniform ? sh : bins + (size_t)nd * kBinWords;
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            float base, k;
+            sah_axis(nbn, a, base, k);
+            if (k == 0.0f) continue;  // no extent on this axis: not a candidate
+            uint32_t *cell = dst + ((uint32_t)a * kSahBins + sah_bin(centroid[3 * (size_t)t + a], base, k)) * 7u;
+            atomicAdd(cell, 1u);
+#pragma unroll
+            for (int x = 0; x < 3; x++) {
+                atomicMin(cell + 1 + x, f2key(b.lo[x]));
+                atomicMax(cell + 4 + x, f2key(b.hi[x]));
+            }
+        }
+    }
+    if (uniform) {
+        __syncthreads();
+        uint32_t *dst = bins + (size_t)s0 * kBinWords;
+        for (uint32_t w = threadIdx.x; w < kBinWords; w += kB) {
+            const uint32_t v = sh[w], f = w % 7u;
+            if (f == 0) { if (v) atomicAdd(dst + w, v); }
+            else if (f < 4) { if (v != 0xffffffffu) atomicMin(dst + w, v); }
+            else if (v) atomicMax(dst + w, v);
+        }
+    }
+}
+__device__ __forceinline__ Box key_box(const uint32_t *lo, const uint32_t *hi) {
+    Box b;
+#pragma unroll
+    for (int a = 0; a < 3; a++) { b.lo[a] = key2f(lo[a]); b.hi[a] = key2f(hi[a]); }
+    return b;
+}
+__device__ __forceinline__ Box empty_box() {
+    Box b;
+#pragma unroll
+    for (int a = 0; a < 3; a++) { b.lo[a] = INFINITY; b.hi[a] = -INFINITY; }
+    return b;
+}
+// one thread per node of the level: the split, the binary node, the children (next level / small-subtree job / leaf)
+__global__ __launch_bounds__(kB) void k_sah_split(const ANode *active, uint32_t n_active, uint32_t level, const uint32_t *nb, const uint32_t *bins,
+                                                  PNode *bin, Box *node_box, uint32_t *node_depth, uint32_t *counters, SplitRec *split, uint32_t *cursors,
+                                                  ANode *next, Job *jobs) {
+    const uint32_t i = blockIdx.x * kB + threadIdx.x;
+    if (i >= n_active) return;
+    const ANode nd = active[i];
+    const uint32_t n = nd.hi - nd.lo;
+    const uint32_t *nbn = nb + (size_t)i * kNbWords;
+    const uint32_t *bn = bins + (size_t)i * kBinWords;
+    int best_axis = -1;
+    uint32_t best_bin = 0, best_left = 0;
+    float best_cost = 3.0e38f;
+    if (level < 40) {
+        for (int a = 0; a < 3; a++) {
+            float base, k;
+            sah_axis(nbn, a, base, k);
+            if (k == 0.0f) continue;
+            float right_area[kSahBins];
+            uint32_t right_cnt[kSahBins];
+            Box acc = empty_box();
+            uint32_t c = 0;
+            for (int b = (int)kSahBins - 1; b > 0; b--) {
+                const uint32_t *cell = bn + ((uint32_t)a * kSahBins + (uint32_t)b) * 7u;
+                if (cell[0]) acc = merge(acc, key_box(cell + 1, cell + 4));
+                c += cell[0];
+                right_area[b] = c ? area(acc) : 0.0f;
+                right_cnt[b] = c;
+            }
+            acc = empty_box();
+            c = 0;
+            for (int b = 0; b < (int)kSahBins - 1; b++) {
+                const uint32_t *cell = bn + ((uint32_t)a * kSahBins + (uint32_t)b) * 7u;
+                if (cell[0]) acc = merge(acc, key_box(cell + 1, cell + 4));
+                c += cell[0];
+                if (c == 0 || right_cnt[b + 1] == 0) continue;
+                const float cost = area(acc) * (float)((c + 3u) / 4u) + right_area[b + 1] * (float)((right_cnt[b + 1] + 3u) / 4u);
+                if (cost < best_cost) { best_cost = cost; best_axis = a; best_bin = (uint32_t)b; best_left = c; }
+            }
+        }
+    }
+    SplitRec sr;
+    sr.axis = best_axis;
+    sr.bin = best_bin;
+    sr.mid = best_axis >= 0 ? nd.lo + best_left : nd.lo + n / 2;  // coincident centroids or depth guard: halves by position
+    const uint32_t id = atomicAdd(&counters[SC_NODES], 1u);
+    node_box[id] = key_box(nbn, nbn + 3);
+    node_depth[id] = level;
+    atomicMax(&counters[SC_DEPTH], level);
+    bin[id].size = n;
+    if (nd.parent == kNone) counters[SC_ROOT] = id;
+    else (&bin[nd.parent].left)[nd.side] = id;
+    for (uint32_t sd = 0; sd < 2; sd++) {
+        const uint32_t lo = sd ? sr.mid : nd.lo, hi = sd ? nd.hi : sr.mid, cnt = hi - lo;
+        sr.slot[sd] = kNone;
+        if (cnt == 1) {
+            (&bin[id].left)[sd] = 0x80000000u | lo;
+        } else if (cnt <= kSmall) {
+            const uint32_t j = atomicAdd(&counters[SC_JOBS], 1u);
+            jobs[j] = Job{lo, hi, id, sd, level + 1u, {0u, 0u, 0u}};
+        } else {
+            const uint32_t j = atomicAdd(&counters[SC_NEXT], 1u);
+            next[j] = ANode{lo, hi, id, sd};
+            sr.slot[sd] = j;
+        }
+    }
+    split[i] = sr;
+    cursors[2 * i] = nd.lo;
+    cursors[2 * i + 1] = sr.mid;
+}
+__global__ __launch_bounds__(kB) void k_sah_partition(const uint32_t *order, const uint32_t *seg, uint32_t n, const float *centroid, const uint32_t *nb,
+                                                      const SplitRec *split, uint32_t *cursors, uint32_t *order_out, uint32_t *seg_out) {
+    __shared__ uint32_t sh_cnt[2], sh_base[2], sh_rank[2];
+    const uint32_t c0 = blockIdx.x * kChunk, c1 = min(n, c0 + kChunk);
+    const uint32_t s0 = seg[c0], s1 = seg[c1 - 1];
+    const bool uniform = s0 == s1 && s0 != kNone;  // (see k_sah_bounds)
+    if (uniform && split[s0].axis >= 0) {  // one node: count the sides, reserve both runs with ONE atomic each
+        const SplitRec sr = split[s0];
+        float base, k;
+        sah_axis(nb + (size_t)s0 * kNbWords, sr.axis, base, k);
+        if (threadIdx.x < 2) sh_cnt[threadIdx.x] = sh_rank[threadIdx.x] = 0u;
+        __syncthreads();
+        uint32_t mine[2] = {0u, 0u};
+        for (uint32_t p = c0 + threadIdx.x; p < c1; p += kB) {
+            const uint32_t t = order[p];
+            mine[sah_bin(centroid[3 * (size_t)t + sr.axis], base, k) <= sr.bin ? 0 : 1]++;
+        }
+        if (mine[0]) atomicAdd(&sh_cnt[0], mine[0]);
+        if (mine[1]) atomicAdd(&sh_cnt[1], mine[1]);
+        __syncthreads();
+        if (threadIdx.x < 2) sh_base[threadIdx.x] = sh_cnt[threadIdx.x] ? atomicAdd(&cursors[2 * s0 + threadIdx.x], sh_cnt[threadIdx.x]) : 0u;
+        __syncthreads();
+        for (uint32_t p = c0 + threadIdx.x; p < c1; p += kB) {
+            const uint32_t t = order[p];
+            const uint32_t sd = sah_bin(centroid[3 * (size_t)t + sr.axis], base, k) <= sr.bin ? 0u : 1u;
+            const uint32_t q = sh_base[sd] + atomicAdd(&sh_rank[sd], 1u);
+            order_out[q] = t;
+            seg_out[q] = sr.slot[sd];
+        }
+        return;
+    }
+    for (uint32_t p = c0 + threadIdx.x; p < c1; p += kB) {
+        const uint32_t nd = seg[p];
+        const uint32_t t = order[p];
+        if (nd == kNone) { order_out[p] = t; seg_out[p] = kNone; continue; }
+        const SplitRec sr = split[nd];
+        uint32_t sd, q;
+        if (sr.axis < 0) {
+            sd = p < sr.mid ? 0u : 1u;
+            q = p;
+        } else {
+            float base, k;
+            sah_axis(nb + (size_t)nd * kNbWords, sr.axis, base, k);
+            sd = sah_bin(centroid[3 * (size_t)t + sr.axis], base, k) <= sr.bin ? 0u : 1u;
+            q = atomicAdd(&cursors[2 * nd + sd], 1u);
+        }
+        order_out[q] = t;
+        seg_out[q] = sr.slot[sd];
+    }
+}
+// One wave (= one 64-thread workgroup) per subtree of 2 .. 64 triangles, one triangle per lane.  Every round splits every segment
+// of two or more lanes: lane i proposes, on each axis, the plane behind its own centroid (left = the lanes of its segment that
+// come before it in (centroid, lane) order, itself included), the segment takes the cheapest proposal, its lanes are
+// rearranged left | right.  The binary node of a split at lane boundary m is base + m - 1 (every boundary is cut exactly once).
+struct SmallLane {
+    uint32_t t, s, e, par, side, dep;
+    Box b;
+    float c[3];
+};
+__device__ __forceinline__ float lane_f(float v, uint32_t j) { return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), (int)j)); }
+__global__ __launch_bounds__(64) void k_sah_small(const Job *jobs, uint32_t n_jobs, const Box *prim_box, const float *centroid, uint32_t *order, PNode *bin,
+                                                  Box *node_box, uint32_t *node_depth, uint32_t *counters) {
+    __shared__ SmallLane sh[64];
+    if (blockIdx.x >= n_jobs) return;
+    const Job jb = jobs[blockIdx.x];
+    const uint32_t n = jb.hi - jb.lo, lane = threadIdx.x;
+    SmallLane me;
+    me.t = 0; me.s = lane; me.e = lane + 1u; me.par = kNone; me.side = 0; me.dep = jb.depth;
+    me.b = empty_box();
+    me.c[0] = me.c[1] = me.c[2] = 0.0f;
+    if (lane < n) {
+        me.t = order[jb.lo + lane];
+        me.b = prim_box[me.t];
+        for (int a = 0; a < 3; a++) me.c[a] = centroid[3 * (size_t)me.t + a];
+        me.s = 0; me.e = n; me.par = jb.parent; me.side = jb.side;
+    }
+    uint32_t base = lane == 0 ? atomicAdd(&counters[SC_NODES], n - 1u) : 0u;
+    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+    for (uint32_t round = 0; round < 64; round++) {
+        const bool splitting = me.e - me.s >= 2u;
+        if (!__ballot(splitting)) break;
+        float best_cost = 3.0e38f;
+        int best_axis = 0;
+        uint32_t best_left = 0;
+        Box seg_box = empty_box();
+        for (int a = 0; a < 3; a++) {
+            Box L = empty_box(), R = empty_box();
+            uint32_t cl = 0, cr = 0;
+            const float mine = a == 0 ? me.c[0] : (a == 1 ? me.c[1] : me.c[2]);
+            for (uint32_t j = 0; j < n; j++) {
+                const float cj = lane_f(a == 0 ? me.c[0] : (a == 1 ? me.c[1] : me.c[2]), j);
+                Box bj;
+#pragma unroll
+                for (int x = 0; x < 3; x++) { bj.lo[x] = lane_f(me.b.lo[x], j); bj.hi[x] = lane_f(me.b.hi[x], j); }
+                const bool in_seg = j >= me.s && j < me.e;
+                const bool left = cj < mine || (cj == mine && j <= lane);
+                if (in_seg && left) { L = merge(L, bj); cl++; }
+                if (in_seg && !left) { R = merge(R, bj); cr++; }
+            }
+            const float cost = cr ? area(L) * (float)((cl + 3u) / 4u) + area(R) * (float)((cr + 3u) / 4u) : 3.0e38f;
+            if (cost < best_cost) { best_cost = cost; best_axis = a; best_left = cl; }
+            seg_box = merge(L, R);  // (whatever the plane: the whole segment)
+        }
+        // the segment's cheapest proposal (lowest lane among equals)
+        float wcost = best_cost;
+        uint32_t w = lane;
+        for (uint32_t j = 0; j < n; j++) {
+            const float cj = lane_f(best_cost, j);
+            if (j >= me.s && j < me.e && (cj < wcost || (cj == wcost && j < w))) { wcost = cj; w = j; }
+        }
+        const bool none = !(wcost < 3.0e38f);  // (boxes whose area overflows: halves by lane)
+        if (none) w = me.s;
+        const int wa = __shfl(best_axis, (int)w, 64);
+        const uint32_t wl = none ? (me.e - me.s) / 2u : (uint32_t)__shfl((int)best_left, (int)w, 64);
+        const float wc0 = __shfl(me.c[0], (int)w, 64), wc1 = __shfl(me.c[1], (int)w, 64), wc2 = __shfl(me.c[2], (int)w, 64);
+        const float wc = wa == 0 ? wc0 : (wa == 1 ? wc1 : wc2), ck = wa == 0 ? me.c[0] : (wa == 1 ? me.c[1] : me.c[2]);
+        const bool left = none ? lane < me.s + wl : (ck < wc || (ck == wc && lane <= w));
+        const uint32_t len = me.e - me.s;
+        const unsigned long long seg_mask = (len >= 64u ? ~0ull : ((1ull << len) - 1ull)) << me.s;
+        const unsigned long long lm = __ballot(left) & seg_mask, below = (1ull << lane) - 1ull;
+        const uint32_t m = me.s + wl;  // the boundary this split cuts
+        uint32_t pos = lane;
+        if (splitting) pos = left ? me.s + (uint32_t)__popcll(lm & below) : m + (uint32_t)__popcll(~lm & seg_mask & below);
+        if (splitting && lane == w) {  // the proposer writes the node
+            const uint32_t id = base + m - 1u;
+            node_box[id] = seg_box;
+            node_depth[id] = me.dep;
+            atomicMax(&counters[SC_DEPTH], me.dep);
+            bin[id].size = len;
+            if (me.par == kNone) counters[SC_ROOT] = id;
+            else (&bin[me.par].left)[me.side] = id;
+            if (wl == 1u) bin[id].left = 0x80000000u | (jb.lo + me.s);
+            if (me.e - m == 1u) bin[id].right = 0x80000000u | (jb.lo + me.e - 1u);
+        }
+        if (splitting) {
+            me.par = base + m - 1u;
+            me.side = left ? 0u : 1u;
+            me.dep++;
+            if (left) me.e = m; else me.s = m;
+        }
+        sh[pos] = me;
+        __syncthreads();
+        me = sh[lane];
+        __syncthreads();
+    }
+    if (lane < n) order[jb.lo + lane] = me.t;
+}
+
+// Every link of the finished binary tree is checked before anything walks it (a wild reference would be a GPU fault in the
+// kernels that follow): references in range, sizes adding up, depths increasing by one, boxes finite and containing their children.
+// bad[0..5]: left / right reference out of range, size, depth, box containment, box not finite.
+__global__ __launch_bounds__(kB) void k_sah_validate(const PNode *bin, const Box *node_box, const uint32_t *node_depth, uint32_t n_int, uint32_t n,
+                                                     const Box *prim_box, const uint32_t *index, uint32_t root, uint32_t *bad) {
+    const uint32_t id = blockIdx.x * kB + threadIdx.x;
+    if (id >= n_int) return;
+    const PNode nd = bin[id];
+    const Box me = node_box[id];
+    bool finite = true;
+    for (int a = 0; a < 3; a++) finite = finite && fabsf(me.lo[a]) < 3.0e38f && fabsf(me.hi[a]) < 3.0e38f && me.lo[a] <= me.hi[a];
+    if (!finite) atomicAdd(&bad[5], 1u);
+    uint32_t total = 0;
+    for (int sd = 0; sd < 2; sd++) {
+        const uint32_t ref = sd ? nd.right : nd.left;
+        Box cb;
+        if (ref & 0x80000000u) {
+            const uint32_t pos = ref & 0x7fffffffu;
+            if (pos >= n || index[pos] >= n) { atomicAdd(&bad[sd], 1u); continue; }
+            cb = prim_box[index[pos]];
+            total += 1u;
+        } else {
+            if (ref >= n_int || ref == id || ref == root) { atomicAdd(&bad[sd], 1u); continue; }
+            cb = node_box[ref];
+            total += bin[ref].size;
+            if (node_depth[ref] != node_depth[id] + 1u) atomicAdd(&bad[3], 1u);
+        }
+        bool inside = true;
+        for (int a = 0; a < 3; a++) inside = inside && cb.lo[a] >= me.lo[a] && cb.hi[a] <= me.hi[a];
+        if (!inside) atomicAdd(&bad[4], 1u);
+    }
+    if (total != nd.size) atomicAdd(&bad[2], 1u);
+}
+
 struct Tmp {
     void *p = nullptr;
     ~Tmp() { if (p) (void)hipFree(p); }
@@ -478,102 +901,235 @@ static int build_nodes(hipStream_t stream, const rthip_tri *d_tris, uint32_t n, 
         info->depth = 0;
         return 0;
     }
-    // Morton order
-    Tmp code_in, code_out, idx_in, idx_out, sort_tmp;
-    BHIP(code_in.alloc(sizeof(unsigned long long) * (size_t)n));
-    BHIP(code_out.alloc(sizeof(unsigned long long) * (size_t)n));
-    BHIP(idx_in.alloc(sizeof(uint32_t) * (size_t)n));
-    BHIP(idx_out.alloc(sizeof(uint32_t) * (size_t)n));
-    hipLaunchKernelGGL(k_morton, dim3(grid_n), dim3(kB), 0, stream, centroid.as<float>(), n, red.as<uint32_t>(), code_in.as<unsigned long long>(), idx_in.as<uint32_t>());
-    size_t sort_bytes = 0;
-    BHIP(rocprim::radix_sort_pairs(nullptr, sort_bytes, code_in.as<unsigned long long>(), code_out.as<unsigned long long>(), idx_in.as<uint32_t>(),
-                                   idx_out.as<uint32_t>(), (size_t)n, 0u, 63u, stream));
-    BHIP(sort_tmp.alloc(sort_bytes));
-    BHIP(rocprim::radix_sort_pairs(sort_tmp.p, sort_bytes, code_in.as<unsigned long long>(), code_out.as<unsigned long long>(), idx_in.as<uint32_t>(),
-                                   idx_out.as<uint32_t>(), (size_t)n, 0u, 63u, stream));
-    const uint32_t *index = idx_out.as<uint32_t>();  // sorted position -> triangle
-
-    // PLOC: cluster arrays ping-pong between A (current) and B (merged, before compaction)
+    // the binary tree: top-down binned SAH (the host builder's algorithm; default) or PLOC clustering (RTHIP_BVH_BUILDER=ploc)
+    bool sah = true;
+    if (const char *e = getenv("RTHIP_BVH_BUILDER")) sah = strcmp(e, "ploc") != 0;
     const uint32_t n_int = n - 1;
-    Tmp bin, node_box, counters, boxA, refA, sizeA, boxB, refB, sizeB, nn, valid, pos, scan_tmp;
+    Tmp bin, node_box, counters, plan, idx_out;
     BHIP(bin.alloc(sizeof(PNode) * (size_t)n_int));
     BHIP(node_box.alloc(sizeof(Box) * (size_t)n_int));
+    BHIP(plan.alloc(sizeof(Plan) * (size_t)n_int));
+    BHIP(idx_out.alloc(sizeof(uint32_t) * (size_t)n));
     BHIP(counters.alloc(256));
-    BHIP(boxA.alloc(sizeof(Box) * (size_t)n));
-    BHIP(boxB.alloc(sizeof(Box) * (size_t)n));
-    BHIP(refA.alloc(sizeof(uint32_t) * (size_t)n));
-    BHIP(refB.alloc(sizeof(uint32_t) * (size_t)n));
-    BHIP(sizeA.alloc(sizeof(uint32_t) * (size_t)n));
-    BHIP(sizeB.alloc(sizeof(uint32_t) * (size_t)n));
-    BHIP(nn.alloc(sizeof(uint32_t) * (size_t)n));
-    BHIP(valid.alloc(sizeof(uint32_t) * (size_t)n));
-    BHIP(pos.alloc(sizeof(uint32_t) * (size_t)n));
-    size_t scan_bytes = 0;
-    BHIP(rocprim::exclusive_scan(nullptr, scan_bytes, valid.as<uint32_t>(), pos.as<uint32_t>(), 0u, (size_t)n, rocprim::plus<uint32_t>(), stream));
-    BHIP(scan_tmp.alloc(scan_bytes));
     uint32_t *cnt = counters.as<uint32_t>();  // [0] wide nodes, [1] next items, [2] overflow, [3] big binary nodes, [4] binary nodes, [5] clusters left
     {
         const uint32_t zeros[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         BHIP(hipMemcpyAsync(cnt, zeros, sizeof zeros, hipMemcpyHostToDevice, stream));
         BHIP(hipStreamSynchronize(stream));
     }
-    hipLaunchKernelGGL(k_ploc_init, dim3(grid_n), dim3(kB), 0, stream, prim_box.as<Box>(), index, n, boxA.as<Box>(), refA.as<uint32_t>(), sizeA.as<uint32_t>());
-    uint32_t nc = n;
-    int radius = 16;
-    if (const char *e = getenv("RTHIP_PLOC_RADIUS")) radius = atoi(e) < 1 ? 1 : (atoi(e) > kRadiusMax ? kRadiusMax : atoi(e));
-    // (Passes that first form leaves of at most four triangles - leaf_limit = 4 - fill the leaves better, 3.6 instead of 3.1
-    // triangles, but the greedy groups have worse boxes: 4 % more traversal steps and 8 % slower frames on config 4.  Off.)
-    uint32_t leaf_limit = 0;
-    std::vector<uint32_t> made;  // binary nodes in existence after every clustering pass
-    for (int pass = 0; nc > 1; pass++) {
-        if (pass > 4096) {
-            snprintf(err, err_len, "BVH build: clustering did not converge (%u clusters left)", nc);
-            return RTHIP_E_UNSUPPORTED;  // (the caller may build this BVH on the host instead)
-        }
-        const uint32_t g = (nc + kB - 1) / kB;
-        hipLaunchKernelGGL(k_ploc_nn, dim3(g), dim3(kB), 0, stream, boxA.as<Box>(), sizeA.as<uint32_t>(), nc, nn.as<uint32_t>(), radius, leaf_limit);
-        hipLaunchKernelGGL(k_ploc_merge, dim3(g), dim3(kB), 0, stream, nn.as<uint32_t>(), boxA.as<Box>(), refA.as<uint32_t>(), sizeA.as<uint32_t>(), nc, bin.as<PNode>(),
-                           node_box.as<Box>(), cnt + 4, valid.as<uint32_t>(), boxB.as<Box>(), refB.as<uint32_t>(), sizeB.as<uint32_t>());
-        BHIP(rocprim::exclusive_scan(scan_tmp.p, scan_bytes, valid.as<uint32_t>(), pos.as<uint32_t>(), 0u, (size_t)nc, rocprim::plus<uint32_t>(), stream));
-        hipLaunchKernelGGL(k_ploc_compact, dim3(g), dim3(kB), 0, stream, valid.as<uint32_t>(), pos.as<uint32_t>(), boxB.as<Box>(), refB.as<uint32_t>(), sizeB.as<uint32_t>(), nc,
-                           boxA.as<Box>(), refA.as<uint32_t>(), sizeA.as<uint32_t>(), cnt + 5);
-        uint32_t left = 0, made_now = 0;
-        BHIP(hipMemcpyAsync(&left, cnt + 5, sizeof left, hipMemcpyDeviceToHost, stream));
-        BHIP(hipMemcpyAsync(&made_now, cnt + 4, sizeof made_now, hipMemcpyDeviceToHost, stream));
-        BHIP(hipStreamSynchronize(stream));
-        made.push_back(made_now);
-        if (leaf_limit && left == nc) {  // no pair of at most four triangles left: on to the tree above the leaves
-            leaf_limit = 0;
-            continue;
-        }
-        if (left == 0 || left >= nc) {  // (every unrestricted pass merges at least the globally closest pair)
-            snprintf(err, err_len, "BVH build: clustering pass %d went from %u to %u clusters", pass, nc, left);
-            return RTHIP_E_HIP;
-        }
-        nc = left;
-    }
+    const uint32_t *index = nullptr;
     uint32_t root_ref = 0;
-    BHIP(hipMemcpyAsync(&root_ref, refA.p, sizeof root_ref, hipMemcpyDeviceToHost, stream));
-    BHIP(hipStreamSynchronize(stream));
-    if (root_ref & 0x80000000u) {
-        snprintf(err, err_len, "BVH build: the clustering left a triangle as the root");
-        return RTHIP_E_HIP;
-    }
-    // the collapse plan, bottom-up in the order the clustering made the nodes (a pass only merges clusters of earlier passes)
-    Tmp plan;
-    BHIP(plan.alloc(sizeof(Plan) * (size_t)n_int));
-    {
-        uint32_t from = 0;
-        for (uint32_t upto : made) {
-            if (upto > from)
-                hipLaunchKernelGGL(k_plan, dim3((upto - from + kB - 1) / kB), dim3(kB), 0, stream, from, upto, bin.as<PNode>(), node_box.as<Box>(), prim_box.as<Box>(),
-                                   index, plan.as<Plan>());
-            from = upto;
+    if (!sah) {
+        // Morton order
+        Tmp code_in, code_out, idx_in, sort_tmp;
+        BHIP(code_in.alloc(sizeof(unsigned long long) * (size_t)n));
+        BHIP(code_out.alloc(sizeof(unsigned long long) * (size_t)n));
+        BHIP(idx_in.alloc(sizeof(uint32_t) * (size_t)n));
+        hipLaunchKernelGGL(k_morton, dim3(grid_n), dim3(kB), 0, stream, centroid.as<float>(), n, red.as<uint32_t>(), code_in.as<unsigned long long>(), idx_in.as<uint32_t>());
+        size_t sort_bytes = 0;
+        BHIP(rocprim::radix_sort_pairs(nullptr, sort_bytes, code_in.as<unsigned long long>(), code_out.as<unsigned long long>(), idx_in.as<uint32_t>(),
+                                       idx_out.as<uint32_t>(), (size_t)n, 0u, 63u, stream));
+        BHIP(sort_tmp.alloc(sort_bytes));
+        BHIP(rocprim::radix_sort_pairs(sort_tmp.p, sort_bytes, code_in.as<unsigned long long>(), code_out.as<unsigned long long>(), idx_in.as<uint32_t>(),
+                                       idx_out.as<uint32_t>(), (size_t)n, 0u, 63u, stream));
+        index = idx_out.as<uint32_t>();  // sorted position -> triangle
+
+        // PLOC: cluster arrays ping-pong between A (current) and B (merged, before compaction)
+        Tmp boxA, refA, sizeA, boxB, refB, sizeB, nn, valid, pos, scan_tmp;
+        BHIP(boxA.alloc(sizeof(Box) * (size_t)n));
+        BHIP(boxB.alloc(sizeof(Box) * (size_t)n));
+        BHIP(refA.alloc(sizeof(uint32_t) * (size_t)n));
+        BHIP(refB.alloc(sizeof(uint32_t) * (size_t)n));
+        BHIP(sizeA.alloc(sizeof(uint32_t) * (size_t)n));
+        BHIP(sizeB.alloc(sizeof(uint32_t) * (size_t)n));
+        BHIP(nn.alloc(sizeof(uint32_t) * (size_t)n));
+        BHIP(valid.alloc(sizeof(uint32_t) * (size_t)n));
+        BHIP(pos.alloc(sizeof(uint32_t) * (size_t)n));
+        size_t scan_bytes = 0;
+        BHIP(rocprim::exclusive_scan(nullptr, scan_bytes, valid.as<uint32_t>(), pos.as<uint32_t>(), 0u, (size_t)n, rocprim::plus<uint32_t>(), stream));
+        BHIP(scan_tmp.alloc(scan_bytes));
+        hipLaunchKernelGGL(k_ploc_init, dim3(grid_n), dim3(kB), 0, stream, prim_box.as<Box>(), index, n, boxA.as<Box>(), refA.as<uint32_t>(), sizeA.as<uint32_t>());
+        uint32_t nc = n;
+        int radius = 16;
+        if (const char *e = getenv("RTHIP_PLOC_RADIUS")) radius = atoi(e) < 1 ? 1 : (atoi(e) > kRadiusMax ? kRadiusMax : atoi(e));
+        // (Passes that first form leaves of at most four triangles - leaf_limit = 4 - fill the leaves better, 3.6 instead of 3.1
+        // triangles, but the greedy groups have worse boxes: 4 % more traversal steps and 8 % slower frames on config 4.  Off.)
+        uint32_t leaf_limit = 0;
+        std::vector<uint32_t> made;  // binary nodes in existence after every clustering pass
+        for (int pass = 0; nc > 1; pass++) {
+            if (pass > 4096) {
+                snprintf(err, err_len, "BVH build: clustering did not converge (%u clusters left)", nc);
+                return RTHIP_E_UNSUPPORTED;  // (the caller may build this BVH on the host instead)
+            }
+            const uint32_t g = (nc + kB - 1) / kB;
+            hipLaunchKernelGGL(k_ploc_nn, dim3(g), dim3(kB), 0, stream, boxA.as<Box>(), sizeA.as<uint32_t>(), nc, nn.as<uint32_t>(), radius, leaf_limit);
+            hipLaunchKernelGGL(k_ploc_merge, dim3(g), dim3(kB), 0, stream, nn.as<uint32_t>(), boxA.as<Box>(), refA.as<uint32_t>(), sizeA.as<uint32_t>(), nc, bin.as<PNode>(),
+                               node_box.as<Box>(), cnt + 4, valid.as<uint32_t>(), boxB.as<Box>(), refB.as<uint32_t>(), sizeB.as<uint32_t>());
+            BHIP(rocprim::exclusive_scan(scan_tmp.p, scan_bytes, valid.as<uint32_t>(), pos.as<uint32_t>(), 0u, (size_t)nc, rocprim::plus<uint32_t>(), stream));
+            hipLaunchKernelGGL(k_ploc_compact, dim3(g), dim3(kB), 0, stream, valid.as<uint32_t>(), pos.as<uint32_t>(), boxB.as<Box>(), refB.as<uint32_t>(), sizeB.as<uint32_t>(), nc,
+                               boxA.as<Box>(), refA.as<uint32_t>(), sizeA.as<uint32_t>(), cnt + 5);
+            uint32_t left = 0, made_now = 0;
+            BHIP(hipMemcpyAsync(&left, cnt + 5, sizeof left, hipMemcpyDeviceToHost, stream));
+            BHIP(hipMemcpyAsync(&made_now, cnt + 4, sizeof made_now, hipMemcpyDeviceToHost, stream));
+            BHIP(hipStreamSynchronize(stream));
+            made.push_back(made_now);
+            if (leaf_limit && left == nc) {  // no pair of at most four triangles left: on to the tree above the leaves
+                leaf_limit = 0;
+                continue;
+            }
+            if (left == 0 || left >= nc) {  // (every unrestricted pass merges at least the globally closest pair)
+                snprintf(err, err_len, "BVH build: clustering pass %d went from %u to %u clusters", pass, nc, left);
+                return RTHIP_E_HIP;
+            }
+            nc = left;
         }
-        if (from != n_int) {
-            snprintf(err, err_len, "BVH build: %u binary nodes made, %u expected", from, n_int);
+        BHIP(hipMemcpyAsync(&root_ref, refA.p, sizeof root_ref, hipMemcpyDeviceToHost, stream));
+        BHIP(hipStreamSynchronize(stream));
+        if (root_ref & 0x80000000u) {
+            snprintf(err, err_len, "BVH build: the clustering left a triangle as the root");
             return RTHIP_E_HIP;
         }
+        // the collapse plan, bottom-up in the order the clustering made the nodes (a pass only merges clusters of earlier passes)
+        {
+            uint32_t from = 0;
+            for (uint32_t upto : made) {
+                if (upto > from)
+                    hipLaunchKernelGGL(k_plan, dim3((upto - from + kB - 1) / kB), dim3(kB), 0, stream, from, upto, bin.as<PNode>(), node_box.as<Box>(), prim_box.as<Box>(),
+                                       index, plan.as<Plan>());
+                from = upto;
+            }
+            if (from != n_int) {
+                snprintf(err, err_len, "BVH build: %u binary nodes made, %u expected", from, n_int);
+                return RTHIP_E_HIP;
+            }
+        }
+    } else {
+        // top-down binned SAH (see k_sah_*): level-synchronous above kSmall triangles, one wave per subtree below
+        const uint32_t a_max = n / (kSmall + 1u) + 2u, j_max = n / 2u + 2u;
+        Tmp order_b, seg_a, seg_b, nb, bins, split, cursors, act_a, act_b, jobs, node_depth, sc;
+        BHIP(order_b.alloc(sizeof(uint32_t) * (size_t)n));
+        BHIP(seg_a.alloc(sizeof(uint32_t) * (size_t)n));
+        BHIP(seg_b.alloc(sizeof(uint32_t) * (size_t)n));
+        BHIP(nb.alloc(sizeof(uint32_t) * kNbWords * (size_t)a_max));
+        BHIP(bins.alloc(sizeof(uint32_t) * kBinWords * (size_t)a_max));
+        BHIP(split.alloc(sizeof(SplitRec) * (size_t)a_max));
+        BHIP(cursors.alloc(sizeof(uint32_t) * 2 * (size_t)a_max));
+        BHIP(act_a.alloc(sizeof(ANode) * (size_t)a_max));
+        BHIP(act_b.alloc(sizeof(ANode) * (size_t)a_max));
+        BHIP(jobs.alloc(sizeof(Job) * (size_t)j_max));
+        BHIP(node_depth.alloc(sizeof(uint32_t) * (size_t)n_int));
+        BHIP(sc.alloc(256));
+        uint32_t *scp = sc.as<uint32_t>();
+        uint32_t *ord_cur = idx_out.as<uint32_t>(), *ord_nxt = order_b.as<uint32_t>();
+        uint32_t *seg_cur = seg_a.as<uint32_t>(), *seg_nxt = seg_b.as<uint32_t>();
+        ANode *act_cur = act_a.as<ANode>(), *act_nxt = act_b.as<ANode>();
+        hipLaunchKernelGGL(k_iota, dim3(grid_n), dim3(kB), 0, stream, ord_cur, n);
+        uint32_t n_active = 0, n_jobs = 0;
+        {
+            const uint32_t zeros[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            BHIP(hipMemcpyAsync(scp, zeros, sizeof zeros, hipMemcpyHostToDevice, stream));
+            if (n > kSmall) {
+                const ANode root = {0u, n, kNone, 0u};
+                BHIP(hipMemcpyAsync(act_cur, &root, sizeof root, hipMemcpyHostToDevice, stream));
+                BHIP(hipMemsetAsync(seg_cur, 0, sizeof(uint32_t) * (size_t)n, stream));
+                n_active = 1;
+            } else {
+                const Job root = {0u, n, kNone, 0u, 0u, {0u, 0u, 0u}};
+                BHIP(hipMemcpyAsync(jobs.p, &root, sizeof root, hipMemcpyHostToDevice, stream));
+                const uint32_t one = 1u;
+                BHIP(hipMemcpyAsync(scp + SC_JOBS, &one, sizeof one, hipMemcpyHostToDevice, stream));
+            }
+            BHIP(hipStreamSynchronize(stream));  // (locals)
+        }
+        const uint32_t grid_c = (n + kChunk - 1) / kChunk;
+        for (uint32_t level = 0; n_active; level++) {
+            if (level > 4096) {
+                snprintf(err, err_len, "BVH build: the top-down build did not end (%u nodes at level %u)", n_active, level);
+                return RTHIP_E_UNSUPPORTED;
+            }
+            const uint32_t words = n_active * kBinWords;
+            hipLaunchKernelGGL(k_sah_clear, dim3((words + kB - 1) / kB), dim3(kB), 0, stream, nb.as<uint32_t>(), bins.as<uint32_t>(), n_active);
+            hipLaunchKernelGGL(k_sah_bounds, dim3(grid_c), dim3(kB), 0, stream, ord_cur, seg_cur, n, prim_box.as<Box>(), centroid.as<float>(), nb.as<uint32_t>());
+            hipLaunchKernelGGL(k_sah_bin, dim3(grid_c), dim3(kB), 0, stream, ord_cur, seg_cur, n, prim_box.as<Box>(), centroid.as<float>(), nb.as<uint32_t>(),
+                               bins.as<uint32_t>());
+            hipLaunchKernelGGL(k_sah_split, dim3((n_active + kB - 1) / kB), dim3(kB), 0, stream, act_cur, n_active, level, nb.as<uint32_t>(), bins.as<uint32_t>(),
+                               bin.as<PNode>(), node_box.as<Box>(), node_depth.as<uint32_t>(), scp, split.as<SplitRec>(), cursors.as<uint32_t>(), act_nxt,
+                               jobs.as<Job>());
+            hipLaunchKernelGGL(k_sah_partition, dim3(grid_c), dim3(kB), 0, stream, ord_cur, seg_cur, n, centroid.as<float>(), nb.as<uint32_t>(),
+                               split.as<SplitRec>(), cursors.as<uint32_t>(), ord_nxt, seg_nxt);
+            uint32_t next_active = 0;
+            BHIP(hipMemcpyAsync(&next_active, scp + SC_NEXT, sizeof next_active, hipMemcpyDeviceToHost, stream));
+            BHIP(hipMemsetAsync(scp + SC_NEXT, 0, sizeof(uint32_t), stream));
+            BHIP(hipStreamSynchronize(stream));
+            if (next_active > a_max) {
+                snprintf(err, err_len, "BVH build: %u nodes at level %u, room for %u", next_active, level + 1, a_max);
+                return RTHIP_E_HIP;
+            }
+            n_active = next_active;
+            std::swap(ord_cur, ord_nxt);
+            std::swap(seg_cur, seg_nxt);
+            std::swap(act_cur, act_nxt);
+        }
+        BHIP(hipMemcpyAsync(&n_jobs, scp + SC_JOBS, sizeof n_jobs, hipMemcpyDeviceToHost, stream));
+        BHIP(hipStreamSynchronize(stream));
+        if (n_jobs > j_max) {
+            snprintf(err, err_len, "BVH build: %u small subtrees, room for %u", n_jobs, j_max);
+            return RTHIP_E_HIP;
+        }
+        if (n_jobs)
+            hipLaunchKernelGGL(k_sah_small, dim3(n_jobs), dim3(64), 0, stream, jobs.as<Job>(), n_jobs, prim_box.as<Box>(), centroid.as<float>(), ord_cur,
+                               bin.as<PNode>(), node_box.as<Box>(), node_depth.as<uint32_t>(), scp);
+        if (ord_cur != idx_out.as<uint32_t>())
+            BHIP(hipMemcpyAsync(idx_out.p, ord_cur, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToDevice, stream));
+        index = idx_out.as<uint32_t>();  // position -> triangle
+        uint32_t sc_h[8];
+        BHIP(hipMemcpyAsync(sc_h, scp, sizeof sc_h, hipMemcpyDeviceToHost, stream));
+        BHIP(hipStreamSynchronize(stream));
+        if (sc_h[SC_NODES] != n_int) {
+            snprintf(err, err_len, "BVH build: %u binary nodes made, %u expected", sc_h[SC_NODES], n_int);
+            return RTHIP_E_HIP;
+        }
+        root_ref = sc_h[SC_ROOT];
+        {
+            BHIP(hipMemsetAsync(scp + 8, 0, sizeof(uint32_t) * 8, stream));
+            if (root_ref < n_int)
+                hipLaunchKernelGGL(k_sah_validate, dim3((n_int + kB - 1) / kB), dim3(kB), 0, stream, bin.as<PNode>(), node_box.as<Box>(), node_depth.as<uint32_t>(),
+                                   n_int, n, prim_box.as<Box>(), index, root_ref, scp + 8);
+            uint32_t bad[8];
+            BHIP(hipMemcpyAsync(bad, scp + 8, sizeof bad, hipMemcpyDeviceToHost, stream));
+            BHIP(hipStreamSynchronize(stream));
+            if (root_ref >= n_int || bad[0] || bad[1] || bad[2] || bad[3] || bad[4] || bad[5]) {
+                snprintf(err, err_len, "BVH build: the binary tree failed its check (root %u of %u; bad left %u right %u size %u depth %u box %u finite %u)",
+                         root_ref, n_int, bad[0], bad[1], bad[2], bad[3], bad[4], bad[5]);
+                return RTHIP_E_UNSUPPORTED;  // (the caller may build this BVH on the host instead)
+            }
+        }
+        {
+            BHIP(hipMemsetAsync(scp + 8, 0, sizeof(uint32_t) * 8, stream));
+            if (root_ref < n_int)
+                hipLaunchKernelGGL(k_sah_validate, dim3((n_int + kB - 1) / kB), dim3(kB), 0, stream, bin.as<PNode>(), node_box.as<Box>(), node_depth.as<uint32_t>(),
+                                   n_int, n, prim_box.as<Box>(), index, root_ref, scp + 8);
+            uint32_t bad[8];
+            BHIP(hipMemcpyAsync(bad, scp + 8, sizeof bad, hipMemcpyDeviceToHost, stream));
+            BHIP(hipStreamSynchronize(stream));
+            if (root_ref >= n_int || bad[0] || bad[1] || bad[2] || bad[3] || bad[4] || bad[5]) {
+                snprintf(err, err_len, "BVH build: the binary tree failed its check (root %u of %u; bad left %u right %u size %u depth %u box %u finite %u)",
+                         root_ref, n_int, bad[0], bad[1], bad[2], bad[3], bad[4], bad[5]);
+                return RTHIP_E_UNSUPPORTED;  // (the caller may build this BVH on the host instead)
+            }
+        }
+        if (getenv("RTHIP_BVH_DEBUG")) {
+            fprintf(stderr, "sah: n %u nodes %u jobs %u root %u depth %u\n", n, sc_h[SC_NODES], n_jobs, root_ref, sc_h[SC_DEPTH]);
+            std::vector<PNode> hb(n_int < 16 ? n_int : 16);
+            std::vector<uint32_t> hd(hb.size());
+            (void)hipMemcpy(hb.data(), bin.p, sizeof(PNode) * hb.size(), hipMemcpyDeviceToHost);
+            (void)hipMemcpy(hd.data(), node_depth.p, sizeof(uint32_t) * hd.size(), hipMemcpyDeviceToHost);
+            for (size_t k = 0; k < hb.size(); k++) fprintf(stderr, "  bin[%zu] left %08x right %08x size %u depth %u\n", k, hb[k].left, hb[k].right, hb[k].size, hd[k]);
+        }
+        for (uint32_t d = sc_h[SC_DEPTH] + 1u; d-- > 0;)  // the collapse plan, deepest nodes first
+            hipLaunchKernelGGL(k_plan_depth, dim3((n_int + kB - 1) / kB), dim3(kB), 0, stream, n_int, d, node_depth.as<uint32_t>(), bin.as<PNode>(),
+                               node_box.as<Box>(), prim_box.as<Box>(), index, plan.as<Plan>());
+        BHIP(hipStreamSynchronize(stream));  // (node_depth and the other temporaries go out of scope)
     }
     // upper bound of the wide nodes: every wide node is made from a different binary node that is not planned as a leaf
     hipLaunchKernelGGL(k_count_interior, dim3((n_int + kB - 1) / kB), dim3(kB), 0, stream, plan.as<Plan>(), n_int, cnt + 3);

@@ -11,6 +11,13 @@ from raytracing_amd import device, host, scenes
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=["sah", "ploc"])
+def builder(request, monkeypatch):
+    """both device builders of the binary tree: top-down binned SAH (the default) and PLOC clustering"""
+    monkeypatch.setenv("RTHIP_BVH_BUILDER", request.param)
+    return request.param
+
+
 def _check_bvh(mesh, nodes, index, verts):
     n_tris = len(index)
     assert mesh.bvh_node_count == len(nodes) and mesh.tri_count == n_tris
@@ -45,7 +52,7 @@ def _check_bvh(mesh, nodes, index, verts):
     assert mesh.abs_max >= np.abs(verts).max()
 
 
-def test_device_built_bvh_of_the_bunny_is_complete_and_conservative(monkeypatch):
+def test_device_built_bvh_of_the_bunny_is_complete_and_conservative(monkeypatch, builder):
     monkeypatch.setenv("RE_BVH_DEVICE_MIN_TRIS", "1")
     hs = host.HostScene(scenes.config(3)[0])
     ctx = device.Context(0)
@@ -58,7 +65,7 @@ def test_device_built_bvh_of_the_bunny_is_complete_and_conservative(monkeypatch)
         ctx.close()
 
 
-def test_device_built_bvh_of_a_height_field_and_of_tiny_meshes():
+def test_device_built_bvh_of_a_height_field_and_of_tiny_meshes(builder):
     v, _ = scenes.heightfield_mesh(384, seed=1234)      # 294 912 triangles: above the host library's 2^18 limit by default
     hs = host.HostScene(scenes.config(4, cells=384)[0])
     ctx = device.Context(0)
@@ -70,13 +77,15 @@ def test_device_built_bvh_of_a_height_field_and_of_tiny_meshes():
         ctx.close()
 
 
-@pytest.mark.parametrize("n_tris", [1, 2, 4, 5, 9])
-def test_device_built_bvh_of_meshes_of_a_few_triangles(monkeypatch, oracle_lib, n_tris):
+@pytest.mark.parametrize("n_tris", [1, 2, 4, 5, 9, 64, 65, 131])
+def test_device_built_bvh_of_meshes_of_a_few_triangles(monkeypatch, oracle_lib, builder, n_tris):
     """(also the regression test of the quad walk's stack size: a BVH that is a lone root pushes up to three children at once;
     the large overlapping triangles here make that happen, and 3 * depth + 1 entries lost hits in both builders' trees)"""
     monkeypatch.setenv("RE_BVH_DEVICE_MIN_TRIS", "1")
     rng = np.random.default_rng(n_tris)
     v = rng.uniform(-2, 2, (n_tris, 9))
+    if n_tris > 64:   # a block of identical triangles: coincident centroids, no plane separates them (split by position)
+        v[10:50] = v[10]
     sd = scenes.SceneDesc("few triangles")
     sd.camera((0, 0, 6))
     sd.mesh(sd.uniform_material(0xffffff, 0.9), v, np.tile([0.0, 0, 1], (n_tris, 3)), scenes.NORMAL_FACE)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Host-built (binned SAH, threads) against device-built (LBVH) 4-wide BVH: scene start-up time and frame time.
+"""Host-built (binned SAH, threads) against device-built (RTHIP_BVH_BUILDER: binned SAH by default, ploc) 4-wide BVH: scene start-up time and frame time.
 usage: gpu_bvh_compare.py [cfg ...]   (default 4 3)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -8,7 +8,7 @@ from raytracing_amd import device, host, scenes
 for cfg in [int(a) for a in sys.argv[1:]] or [4, 3]:
     sd, kw = scenes.config(cfg)
     W, H, MR = kw["width"], kw["height"], kw["max_recursion"]
-    for mode, env in (("host SAH", "0"), ("device LBVH", "1")):
+    for mode, env in (("host SAH", "0"), ("device " + os.environ.get("RTHIP_BVH_BUILDER", "sah"), "1")):
         os.environ["RE_BVH_DEVICE_MIN_TRIS"] = env
         t0 = time.perf_counter()
         hs = host.HostScene(sd); desc = hs.flatten()

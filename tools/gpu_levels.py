@@ -22,7 +22,7 @@ for mr in (range(MR + 1) if counters else (MR,)):
     for _ in range(2): ctx.render_device(cam, prm, fb.data_ptr(), sync=True)
     s = ctx.stats()
     if not counters:
-        print(f"cfg {cfg}: ms_total {s.ms_total:.3f} trace {s.ms_trace:.3f} easy {s.ms_easy:.3f} hard {s.rays_hard}")
+        print(f"cfg {cfg}: ms_total {s.ms_total:.3f} trace {s.ms_trace:.3f} easy {s.ms_easy:.3f} hard {s.rays_hard} checksum {int(fb.to(torch.int64).sum())}")
         for l in range(mr + 1):
             print(f"  level {l}: rays {s.level_rays[l]:9d} walk {s.level_ms_trace[l]:.3f} ms easy {s.level_ms_easy[l]:.3f} ms shade+redo {s.level_ms_shade[l]:.3f} ms")
     else:
