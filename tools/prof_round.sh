@@ -2,7 +2,7 @@
 # One round's measurements on the GPU box: the default bench line, the rocprofv3 kernel-trace stats of the same timed region
 # (`bench.py --no-extras`: only launches of the timed region's size), and the PMC passes (one run per counter group) of the
 # bench's shape of work (config 3, 8-frame calls), of a lone config-4 frame, and the HBM traffic passes.
-# (config 4 with the host-built BVH, the one bench.py reports: RE_BVH_DEVICE_MIN_TRIS=0)
+# (config 4 with the device-built BVH, the library's default for a mesh of that size and the one bench.py reports)
 # usage: bash tools/prof_round.sh <tag>      -> gpurun_out/<tag>_*
 set -u
 export TMPDIR=/tmp
@@ -13,7 +13,7 @@ timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $o/${t
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $o/${tag}_stats_inflight1 -- python3 bench.py --no-extras --no-cpu-baseline --inflight 1 > $o/${tag}_stats_inflight1.json 2> $o/${tag}_stats_inflight1.err || { echo "stats run (inflight 1) failed"; exit 1; }
 bash tools/prof_passes.sh ${tag}_pmc_cfg3_b8 3 4 8 > $o/${tag}_pmc_cfg3_b8.txt 2>&1 || { echo "pmc cfg3 failed"; tail -5 $o/${tag}_pmc_cfg3_b8.txt; exit 1; }
 python3 tools/prof_summary.py $o/${tag}_pmc_cfg3_b8 32 $o/${tag}_pmc_summary_config3_batch8.json > $o/${tag}_pmc_summary_config3_batch8.md
-RE_BVH_DEVICE_MIN_TRIS=0 bash tools/prof_passes.sh ${tag}_pmc_cfg4 4 3 > $o/${tag}_pmc_cfg4.txt 2>&1 || { echo "pmc cfg4 failed"; tail -5 $o/${tag}_pmc_cfg4.txt; exit 1; }
+bash tools/prof_passes.sh ${tag}_pmc_cfg4 4 3 > $o/${tag}_pmc_cfg4.txt 2>&1 || { echo "pmc cfg4 failed"; tail -5 $o/${tag}_pmc_cfg4.txt; exit 1; }
 python3 tools/prof_summary.py $o/${tag}_pmc_cfg4 3 $o/${tag}_pmc_summary_config4.json > $o/${tag}_pmc_summary_config4.md
 bash tools/prof_traffic.sh ${tag}_traffic > $o/${tag}_traffic.txt 2>&1 || { echo "traffic failed"; tail -5 $o/${tag}_traffic.txt; exit 1; }
 echo "round profile done"
