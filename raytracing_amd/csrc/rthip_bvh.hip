@@ -14,7 +14,7 @@
 //                 the chunks that lie inside one node), one wave per subtree of <= 64 triangles (full sweep, a lane per
 //                 triangle); every link of the result is checked (k_sah_validate) before anything walks it.
 //                 (RTHIP_BVH_BUILDER=ploc) k_morton + rocprim radix sort + k_ploc_*: parallel locally-ordered clustering
-//                 (Meister & Bittner 2018) in Morton order - 1.7x faster to build, 22 % slower to walk on config 4
+//                 (Meister & Bittner 2018) in Morton order - as fast to build, 22 % slower to walk on config 4
 //   k_plan      : the optimal collapse of the binary tree to 4-wide nodes and leaves of <= 4 triangles under the surface-area
 //                 cost (bottom-up: by clustering pass / by depth)
 //   k_collapse  : breadth-first, one launch per level, children as planned; leaf order is assigned on the way down; node
@@ -449,11 +449,11 @@ __global__ __launch_bounds__(kB) void k_gather(const rthip_tri *tris, const uint
 // ---------------------------------------------------------------------------------------------------------------------
 // Binary tree by top-down binned SAH on the device - the host builder's algorithm (mesh_build.hpp: 16 bins on each axis over
 // the centroid bounds, cost = area * ceil(count / 4) per side, down to single triangles), level-synchronous for the nodes of
-// more than kSmall triangles (bounds -> bins -> split -> partition, one launch each per level; a 2048-position chunk that lies
-// inside one node accumulates in LDS and flushes once) and one WAVE per subtree of <= kSmall triangles (one triangle per lane,
+// more than kSmall triangles (bounds -> bins -> split -> partition, one launch each per level; a wave's chunk of positions that
+// lies inside one node accumulates in registers / LDS and sends one set of atomics) and one WAVE per subtree of <= kSmall triangles (one triangle per lane,
 // every lane's centroid a candidate plane on each axis: a full sweep).  Positions: `order` holds triangle ids, a node owns a
 // contiguous range; a leaf reference is 0x80000000 | position, as in the clustering builder.
-const uint32_t kSmall = 64, kChunk = 2048, kNone = 0xffffffffu, kSahBins = 16;
+const uint32_t kSmall = 64, kNone = 0xffffffffu, kSahBins = 16;
 const uint32_t kNbWords = 12, kBinWords = 3 * kSahBins * 7;
 struct ANode { uint32_t lo, hi, parent, side; };                   // parent: binary node whose child link this node fills in (kNone: the root)
 struct Job { uint32_t lo, hi, parent, side, depth, pad[3]; };
@@ -471,19 +471,44 @@ __global__ __launch_bounds__(kB) void k_sah_clear(uint32_t *nb, uint32_t *bins, 
         bins[i] = w == 0 ? 0u : (w < 4 ? 0xffffffffu : 0u);
     }
 }
+// A WAVE takes `wchunk` consecutive positions (512 where the nodes are large, 64 at the deep levels).  A node's range is
+// contiguous, so a wave-chunk whose first and last position belong to the same node lies inside it: the wave then accumulates
+// in registers / in its own LDS table and sends ONE set of atomics for the chunk; a mixed chunk sends them per element.
+// (Finished positions - kNone - are not one range: such a chunk is always treated as mixed.)  No workgroup barrier anywhere:
+// the four waves of a workgroup take their own paths.
+struct WaveChunk {
+    uint32_t w0, w1, node;
+    bool uniform;
+};
+__device__ __forceinline__ WaveChunk wave_chunk(const uint32_t *seg, uint32_t n, uint32_t wchunk) {
+    WaveChunk c;
+    const unsigned long long first = (unsigned long long)((blockIdx.x * kB + threadIdx.x) >> 6) * wchunk;
+    c.w0 = first < n ? (uint32_t)first : n;
+    c.w1 = (first + wchunk < n) ? (uint32_t)(first + wchunk) : n;
+    c.node = kNone;
+    c.uniform = false;
+    if (c.w0 < c.w1) {
+        const uint32_t s0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)seg[c.w0]), s1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)seg[c.w1 - 1]);
+        c.node = s0;
+        c.uniform = s0 == s1 && s0 != kNone;
+    }
+    return c;
+}
+__device__ __forceinline__ void wave_lds_sync() {  // this wave's LDS accesses so far are done before the ones that follow (other lanes' included)
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
 // per node: [0..2] / [3..5] min / max keys of the triangle boxes, [6..8] / [9..11] of the centroids
-__global__ __launch_bounds__(kB) void k_sah_bounds(const uint32_t *order, const uint32_t *seg, uint32_t n, const Box *prim_box, const float *centroid,
-                                                   uint32_t *nb) {
-    __shared__ uint32_t sh[kNbWords];
-    const uint32_t c0 = blockIdx.x * kChunk, c1 = min(n, c0 + kChunk);
-    const uint32_t s0 = seg[c0], s1 = seg[c1 - 1];
-    if (s0 == s1 && s0 != kNone) {  // a node's range is contiguous: the whole chunk is its (finished positions are not ONE range)
-        if (threadIdx.x < kNbWords) sh[threadIdx.x] = (threadIdx.x < 3 || (threadIdx.x >= 6 && threadIdx.x < 9)) ? 0xffffffffu : 0u;
-        __syncthreads();
+__global__ __launch_bounds__(kB) void k_sah_bounds(const uint32_t *order, const uint32_t *seg, uint32_t n, uint32_t wchunk, const Box *prim_box,
+                                                   const float *centroid, uint32_t *nb) {
+    const WaveChunk c = wave_chunk(seg, n, wchunk);
+    if (c.w0 >= c.w1) return;
+    const uint32_t lane = threadIdx.x & 63u;
+    if (c.uniform) {
         uint32_t k[kNbWords];
 #pragma unroll
         for (int w = 0; w < (int)kNbWords; w++) k[w] = (w < 3 || (w >= 6 && w < 9)) ? 0xffffffffu : 0u;
-        for (uint32_t p = c0 + threadIdx.x; p < c1; p += kB) {
+        for (uint32_t p = c.w0 + lane; p < c.w1; p += 64u) {
             const uint32_t t = order[p];
             const Box b = prim_box[t];
 #pragma unroll
@@ -503,22 +528,17 @@ __global__ __launch_bounds__(kB) void k_sah_bounds(const uint32_t *order, const 
                 k[w] = (w < 3 || (w >= 6 && w < 9)) ? min(k[w], o) : max(k[w], o);
             }
         }
-        if ((threadIdx.x & 63u) == 0) {
+        if (lane == 0) {
+            uint32_t *dst = nb + (size_t)c.node * kNbWords;
 #pragma unroll
             for (int w = 0; w < (int)kNbWords; w++) {
-                if (w < 3 || (w >= 6 && w < 9)) atomicMin(&sh[w], k[w]);
-                else atomicMax(&sh[w], k[w]);
+                if (w < 3 || (w >= 6 && w < 9)) atomicMin(dst + w, k[w]);
+                else atomicMax(dst + w, k[w]);
             }
-        }
-        __syncthreads();
-        if (threadIdx.x < kNbWords) {
-            uint32_t *dst = nb + (size_t)s0 * kNbWords + threadIdx.x;
-            if (threadIdx.x < 3 || (threadIdx.x >= 6 && threadIdx.x < 9)) atomicMin(dst, sh[threadIdx.x]);
-            else atomicMax(dst, sh[threadIdx.x]);
         }
         return;
     }
-    for (uint32_t p = c0 + threadIdx.x; p < c1; p += kB) {
+    for (uint32_t p = c.w0 + lane; p < c.w1; p += 64u) {
         const uint32_t a_ = seg[p];
         if (a_ == kNone) continue;
         const uint32_t t = order[p];
@@ -549,23 +569,24 @@ __device__ __forceinline__ void sah_axis(const uint32_t *nbn, int a, float &base
     k = hi > lo ? (float)kSahBins / (hi - lo) : 0.0f;
 }
 // per node, axis, bin: count, min keys (3), max keys (3) of the triangle boxes whose centroid falls in the bin
-__global__ __launch_bounds__(kB) void k_sah_bin(const uint32_t *order, const uint32_t *seg, uint32_t n, const Box *prim_box, const float *centroid,
-                                                const uint32_t *nb, uint32_t *bins) {
-    __shared__ uint32_t sh[kBinWords];
-    const uint32_t c0 = blockIdx.x * kChunk, c1 = min(n, c0 + kChunk);
-    const uint32_t s0 = seg[c0], s1 = seg[c1 - 1];
-    const bool uniform = s0 == s1 && s0 != kNone;  // (see k_sah_bounds)
-    if (uniform) {
-        for (uint32_t w = threadIdx.x; w < kBinWords; w += kB) sh[w] = (w % 7u) == 0 ? 0u : ((w % 7u) < 4 ? 0xffffffffu : 0u);
-        __syncthreads();
+__global__ __launch_bounds__(kB) void k_sah_bin(const uint32_t *order, const uint32_t *seg, uint32_t n, uint32_t wchunk, const Box *prim_box,
+                                                const float *centroid, const uint32_t *nb, uint32_t *bins) {
+    __shared__ uint32_t sh_all[kB / 64][kBinWords];
+    const WaveChunk c = wave_chunk(seg, n, wchunk);
+    if (c.w0 >= c.w1) return;
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t *sh = sh_all[threadIdx.x >> 6];
+    if (c.uniform) {
+        for (uint32_t w = lane; w < kBinWords; w += 64u) sh[w] = (w % 7u) == 0 ? 0u : ((w % 7u) < 4 ? 0xffffffffu : 0u);
+        wave_lds_sync();
     }
-    for (uint32_t p = c0 + threadIdx.x; p < c1; p += kB) {
+    for (uint32_t p = c.w0 + lane; p < c.w1; p += 64u) {
         const uint32_t nd = seg[p];
         if (nd == kNone) continue;
         const uint32_t t = order[p];
         const Box b = prim_box[t];
         const uint32_t *nbn = nb + (size_t)nd * kNbWords;
-        uint32_t *dst = uniform ? sh : bins + (size_t)nd * kBinWords;
+        uint32_t *dst = c.uniform ? sh : bins + (size_t)nd * kBinWords;
 #pragma unroll
         for (int a = 0; a < 3; a++) {
             float base, k;
@@ -580,10 +601,10 @@ __global__ __launch_bounds__(kB) void k_sah_bin(const uint32_t *order, const uin
             }
         }
     }
-    if (uniform) {
-        __syncthreads();
-        uint32_t *dst = bins + (size_t)s0 * kBinWords;
-        for (uint32_t w = threadIdx.x; w < kBinWords; w += kB) {
+    if (c.uniform) {
+        wave_lds_sync();
+        uint32_t *dst = bins + (size_t)c.node * kBinWords;
+        for (uint32_t w = lane; w < kBinWords; w += 64u) {
             const uint32_t v = sh[w], f = w % 7u;
             if (f == 0) { if (v) atomicAdd(dst + w, v); }
             else if (f < 4) { if (v != 0xffffffffu) atomicMin(dst + w, v); }
@@ -673,38 +694,46 @@ __global__ __launch_bounds__(kB) void k_sah_split(const ANode *active, uint32_t 
     cursors[2 * i] = nd.lo;
     cursors[2 * i + 1] = sr.mid;
 }
-__global__ __launch_bounds__(kB) void k_sah_partition(const uint32_t *order, const uint32_t *seg, uint32_t n, const float *centroid, const uint32_t *nb,
-                                                      const SplitRec *split, uint32_t *cursors, uint32_t *order_out, uint32_t *seg_out) {
-    __shared__ uint32_t sh_cnt[2], sh_base[2], sh_rank[2];
-    const uint32_t c0 = blockIdx.x * kChunk, c1 = min(n, c0 + kChunk);
-    const uint32_t s0 = seg[c0], s1 = seg[c1 - 1];
-    const bool uniform = s0 == s1 && s0 != kNone;  // (see k_sah_bounds)
-    if (uniform && split[s0].axis >= 0) {  // one node: count the sides, reserve both runs with ONE atomic each
-        const SplitRec sr = split[s0];
+__global__ __launch_bounds__(kB) void k_sah_partition(const uint32_t *order, const uint32_t *seg, uint32_t n, uint32_t wchunk, const float *centroid,
+                                                      const uint32_t *nb, const SplitRec *split, uint32_t *cursors, uint32_t *order_out, uint32_t *seg_out) {
+    const WaveChunk c = wave_chunk(seg, n, wchunk);
+    if (c.w0 >= c.w1) return;
+    const uint32_t lane = threadIdx.x & 63u;
+    if (c.uniform && split[c.node].axis >= 0) {  // one node: count the sides (ballots), reserve both runs with ONE atomic each, keep the order
+        const SplitRec sr = split[c.node];
         float base, k;
-        sah_axis(nb + (size_t)s0 * kNbWords, sr.axis, base, k);
-        if (threadIdx.x < 2) sh_cnt[threadIdx.x] = sh_rank[threadIdx.x] = 0u;
-        __syncthreads();
-        uint32_t mine[2] = {0u, 0u};
-        for (uint32_t p = c0 + threadIdx.x; p < c1; p += kB) {
-            const uint32_t t = order[p];
-            mine[sah_bin(centroid[3 * (size_t)t + sr.axis], base, k) <= sr.bin ? 0 : 1]++;
+        sah_axis(nb + (size_t)c.node * kNbWords, sr.axis, base, k);
+        uint32_t cnt[2] = {0u, 0u};
+        for (uint32_t p0 = c.w0; p0 < c.w1; p0 += 64u) {
+            const uint32_t p = p0 + lane;
+            const bool live = p < c.w1;
+            const bool left = live && sah_bin(centroid[3 * (size_t)order[live ? p : c.w0] + sr.axis], base, k) <= sr.bin;
+            const unsigned long long ml = __ballot(left), mr = __ballot(live && !left);
+            cnt[0] += (uint32_t)__popcll(ml);
+            cnt[1] += (uint32_t)__popcll(mr);
         }
-        if (mine[0]) atomicAdd(&sh_cnt[0], mine[0]);
-        if (mine[1]) atomicAdd(&sh_cnt[1], mine[1]);
-        __syncthreads();
-        if (threadIdx.x < 2) sh_base[threadIdx.x] = sh_cnt[threadIdx.x] ? atomicAdd(&cursors[2 * s0 + threadIdx.x], sh_cnt[threadIdx.x]) : 0u;
-        __syncthreads();
-        for (uint32_t p = c0 + threadIdx.x; p < c1; p += kB) {
-            const uint32_t t = order[p];
-            const uint32_t sd = sah_bin(centroid[3 * (size_t)t + sr.axis], base, k) <= sr.bin ? 0u : 1u;
-            const uint32_t q = sh_base[sd] + atomicAdd(&sh_rank[sd], 1u);
-            order_out[q] = t;
-            seg_out[q] = sr.slot[sd];
+        uint32_t at[2] = {0u, 0u};
+        if (lane < 2u && cnt[lane]) at[lane] = atomicAdd(&cursors[2 * c.node + lane], cnt[lane]);
+        at[0] = (uint32_t)__builtin_amdgcn_readlane((int)at[0], 0);
+        at[1] = (uint32_t)__builtin_amdgcn_readlane((int)at[1], 1);
+        const unsigned long long below = (1ull << lane) - 1ull;
+        for (uint32_t p0 = c.w0; p0 < c.w1; p0 += 64u) {
+            const uint32_t p = p0 + lane;
+            const bool live = p < c.w1;
+            const uint32_t t = order[live ? p : c.w0];
+            const bool left = live && sah_bin(centroid[3 * (size_t)t + sr.axis], base, k) <= sr.bin;
+            const unsigned long long ml = __ballot(left), mr = __ballot(live && !left);
+            if (live) {
+                const uint32_t q = left ? at[0] + (uint32_t)__popcll(ml & below) : at[1] + (uint32_t)__popcll(mr & below);
+                order_out[q] = t;
+                seg_out[q] = sr.slot[left ? 0 : 1];
+            }
+            at[0] += (uint32_t)__popcll(ml);
+            at[1] += (uint32_t)__popcll(mr);
         }
         return;
     }
-    for (uint32_t p = c0 + threadIdx.x; p < c1; p += kB) {
+    for (uint32_t p = c.w0 + lane; p < c.w1; p += 64u) {
         const uint32_t nd = seg[p];
         const uint32_t t = order[p];
         if (nd == kNone) { order_out[p] = t; seg_out[p] = kNone; continue; }
@@ -1041,21 +1070,24 @@ static int build_nodes(hipStream_t stream, const rthip_tri *d_tris, uint32_t n, 
             }
             BHIP(hipStreamSynchronize(stream));  // (locals)
         }
-        const uint32_t grid_c = (n + kChunk - 1) / kChunk;
         for (uint32_t level = 0; n_active; level++) {
             if (level > 4096) {
                 snprintf(err, err_len, "BVH build: the top-down build did not end (%u nodes at level %u)", n_active, level);
                 return RTHIP_E_UNSUPPORTED;
             }
             const uint32_t words = n_active * kBinWords;
+            // positions per wave: 512 while the nodes are large, down to 64 so that the chunks of the deep levels still lie inside one node
+            uint32_t wchunk = 512;
+            while (wchunk > 64 && (unsigned long long)wchunk * 8ull * n_active > n) wchunk >>= 1;
+            const uint32_t grid_c = (uint32_t)((((unsigned long long)n + wchunk - 1) / wchunk + kB / 64 - 1) / (kB / 64));
             hipLaunchKernelGGL(k_sah_clear, dim3((words + kB - 1) / kB), dim3(kB), 0, stream, nb.as<uint32_t>(), bins.as<uint32_t>(), n_active);
-            hipLaunchKernelGGL(k_sah_bounds, dim3(grid_c), dim3(kB), 0, stream, ord_cur, seg_cur, n, prim_box.as<Box>(), centroid.as<float>(), nb.as<uint32_t>());
-            hipLaunchKernelGGL(k_sah_bin, dim3(grid_c), dim3(kB), 0, stream, ord_cur, seg_cur, n, prim_box.as<Box>(), centroid.as<float>(), nb.as<uint32_t>(),
+            hipLaunchKernelGGL(k_sah_bounds, dim3(grid_c), dim3(kB), 0, stream, ord_cur, seg_cur, n, wchunk, prim_box.as<Box>(), centroid.as<float>(), nb.as<uint32_t>());
+            hipLaunchKernelGGL(k_sah_bin, dim3(grid_c), dim3(kB), 0, stream, ord_cur, seg_cur, n, wchunk, prim_box.as<Box>(), centroid.as<float>(), nb.as<uint32_t>(),
                                bins.as<uint32_t>());
             hipLaunchKernelGGL(k_sah_split, dim3((n_active + kB - 1) / kB), dim3(kB), 0, stream, act_cur, n_active, level, nb.as<uint32_t>(), bins.as<uint32_t>(),
                                bin.as<PNode>(), node_box.as<Box>(), node_depth.as<uint32_t>(), scp, split.as<SplitRec>(), cursors.as<uint32_t>(), act_nxt,
                                jobs.as<Job>());
-            hipLaunchKernelGGL(k_sah_partition, dim3(grid_c), dim3(kB), 0, stream, ord_cur, seg_cur, n, centroid.as<float>(), nb.as<uint32_t>(),
+            hipLaunchKernelGGL(k_sah_partition, dim3(grid_c), dim3(kB), 0, stream, ord_cur, seg_cur, n, wchunk, centroid.as<float>(), nb.as<uint32_t>(),
                                split.as<SplitRec>(), cursors.as<uint32_t>(), ord_nxt, seg_nxt);
             uint32_t next_active = 0;
             BHIP(hipMemcpyAsync(&next_active, scp + SC_NEXT, sizeof next_active, hipMemcpyDeviceToHost, stream));
@@ -1103,28 +1135,6 @@ static int build_nodes(hipStream_t stream, const rthip_tri *d_tris, uint32_t n, 
                          root_ref, n_int, bad[0], bad[1], bad[2], bad[3], bad[4], bad[5]);
                 return RTHIP_E_UNSUPPORTED;  // (the caller may build this BVH on the host instead)
             }
-        }
-        {
-            BHIP(hipMemsetAsync(scp + 8, 0, sizeof(uint32_t) * 8, stream));
-            if (root_ref < n_int)
-                hipLaunchKernelGGL(k_sah_validate, dim3((n_int + kB - 1) / kB), dim3(kB), 0, stream, bin.as<PNode>(), node_box.as<Box>(), node_depth.as<uint32_t>(),
-                                   n_int, n, prim_box.as<Box>(), index, root_ref, scp + 8);
-            uint32_t bad[8];
-            BHIP(hipMemcpyAsync(bad, scp + 8, sizeof bad, hipMemcpyDeviceToHost, stream));
-            BHIP(hipStreamSynchronize(stream));
-            if (root_ref >= n_int || bad[0] || bad[1] || bad[2] || bad[3] || bad[4] || bad[5]) {
-                snprintf(err, err_len, "BVH build: the binary tree failed its check (root %u of %u; bad left %u right %u size %u depth %u box %u finite %u)",
-                         root_ref, n_int, bad[0], bad[1], bad[2], bad[3], bad[4], bad[5]);
-                return RTHIP_E_UNSUPPORTED;  // (the caller may build this BVH on the host instead)
-            }
-        }
-        if (getenv("RTHIP_BVH_DEBUG")) {
-            fprintf(stderr, "sah: n %u nodes %u jobs %u root %u depth %u\n", n, sc_h[SC_NODES], n_jobs, root_ref, sc_h[SC_DEPTH]);
-            std::vector<PNode> hb(n_int < 16 ? n_int : 16);
-            std::vector<uint32_t> hd(hb.size());
-            (void)hipMemcpy(hb.data(), bin.p, sizeof(PNode) * hb.size(), hipMemcpyDeviceToHost);
-            (void)hipMemcpy(hd.data(), node_depth.p, sizeof(uint32_t) * hd.size(), hipMemcpyDeviceToHost);
-            for (size_t k = 0; k < hb.size(); k++) fprintf(stderr, "  bin[%zu] left %08x right %08x size %u depth %u\n", k, hb[k].left, hb[k].right, hb[k].size, hd[k]);
         }
         for (uint32_t d = sc_h[SC_DEPTH] + 1u; d-- > 0;)  // the collapse plan, deepest nodes first
             hipLaunchKernelGGL(k_plan_depth, dim3((n_int + kB - 1) / kB), dim3(kB), 0, stream, n_int, d, node_depth.as<uint32_t>(), bin.as<PNode>(),
