@@ -91,12 +91,14 @@ __device__ __forceinline__ float area(const Box &b) {
 
 // reduction cell: [0..2] min centroid keys, [3..5] max centroid keys, [6] max |coordinate| key
 __global__ __launch_bounds__(kB) void k_prims(const rthip_tri *tris, uint32_t n, Box *prim_box, float *centroid, uint32_t *red) {
-    const uint32_t i = blockIdx.x * kB + threadIdx.x;
-    float c[3] = {0, 0, 0}, am = 0.0f;
-    const bool live = i < n;
-    if (live) {
+    // (a bounded grid that strides over the triangles: the seven atomics of every wave go to ONE line, and 32 K waves' worth of
+    // them took 2.3 ms of a 2 M-triangle build)
+    float am = 0.0f;
+    uint32_t kmin[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, kmax[3] = {0u, 0u, 0u};
+    for (uint32_t i = blockIdx.x * kB + threadIdx.x; i < n; i += gridDim.x * kB) {
         const rthip_tri t = tris[i];
         Box b;
+        float c[3];
 #pragma unroll
         for (int k = 0; k < 3; k++) {
             // the vertices as the triangle test sees them: v0, v0 + e0, v0 + e1 (fp64; the outward fp32 rounding plus one ulp
@@ -108,18 +110,15 @@ __global__ __launch_bounds__(kB) void k_prims(const rthip_tri *tris, uint32_t n,
             c[k] = (float)(0.5 * (l + h));
             if (!(fabsf(c[k]) < 3.0e38f)) c[k] = 0.0f;  // (the builders order triangles by centroid: keep it comparable)
             am = fmaxf(am, fmaxf(fabsf(b.lo[k]), fabsf(b.hi[k])));
+            kmin[k] = min(kmin[k], f2key(c[k]));
+            kmax[k] = max(kmax[k], f2key(c[k]));
         }
         prim_box[i] = b;
         centroid[3 * (size_t)i] = c[0];
         centroid[3 * (size_t)i + 1] = c[1];
         centroid[3 * (size_t)i + 2] = c[2];
     }
-    uint32_t kmin[3], kmax[3], kam = f2key(am);
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-        kmin[k] = live ? f2key(c[k]) : 0xffffffffu;
-        kmax[k] = live ? f2key(c[k]) : 0u;
-    }
+    uint32_t kam = f2key(am);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
 #pragma unroll
@@ -913,7 +912,7 @@ static int build_nodes(hipStream_t stream, const rthip_tri *d_tris, uint32_t n, 
         BHIP(hipMemcpyAsync(red.p, init, sizeof init, hipMemcpyHostToDevice, stream));
         BHIP(hipStreamSynchronize(stream));  // `init` is a local
     }
-    hipLaunchKernelGGL(k_prims, dim3(grid_n), dim3(kB), 0, stream, d_tris, n, prim_box.as<Box>(), centroid.as<float>(), red.as<uint32_t>());
+    hipLaunchKernelGGL(k_prims, dim3(grid_n < 2048u ? grid_n : 2048u), dim3(kB), 0, stream, d_tris, n, prim_box.as<Box>(), centroid.as<float>(), red.as<uint32_t>());
     uint32_t red_h[8];
     BHIP(hipMemcpyAsync(red_h, red.p, sizeof red_h, hipMemcpyDeviceToHost, stream));
     BHIP(hipStreamSynchronize(stream));
