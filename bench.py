@@ -6,8 +6,9 @@ A "step" is one frame of the workload: BASELINE.json configs[2], the reference's
 MaxRecursion 3).  The flattened scene is resident in HBM before the timed
 region; every step traces the whole frame.  With N > 1 the frame is partitioned into interleaved
 32x8 screen tiles (tile t -> rank t % N), each rank renders its share into a tile-compact buffer in
-HBM, the buffers are gathered to rank 0 over RCCL (--collective all_gather: to every rank) and assembled into
-the frames on the device; total work
+HBM, the buffers of a call are gathered over RCCL to ONE rank - call k's to rank k % N, so that the receive traffic and the
+assemble kernel go round the ranks (--gather-dst 0: always rank 0; --collective all_gather: to every rank) - and assembled
+into the frames on that rank's device; total work
 is fixed as N grows ("strong" scaling).
 
 Frames are traced in runs: one rthip_render_batch_device call takes --batch frames (default 8 per GPU: 8, 16, 32, 64 on 1, 2, 4, 8 GPUs; the same camera for
@@ -227,6 +228,9 @@ def main():
     ap.add_argument("--no-config4", action="store_true", help="skip the config-4 object (2 M-triangle scene: ~3 s of host build + 0.6 GB upload)")
     ap.add_argument("--collective", choices=["gather", "all_gather"], default="gather", help="framebuffer exchange: gather to rank 0 "
                     "(each peer sends its part once) or all-gather (every rank ends up with the frames)")
+    ap.add_argument("--gather-dst", choices=["rotate", "0"], default="rotate", help="with --collective gather: the rank that receives and "
+                    "assembles call k's frames - k %% N (default: the receive traffic and the assemble kernel go round the ranks, the frames "
+                    "of a call stay in that rank's HBM) or always rank 0 (which then does N times the assembling and bounds the scaling)")
     ap.add_argument("--force-gather", action="store_true", help="run the RCCL gather + assemble path even with one rank")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true", help="torch.distributed.run with N ranks that all use GPU 0 and exchange "
                     "over gloo (staged through host memory): walks the multi-rank control flow of this script on a one-GPU box; the "
@@ -321,7 +325,7 @@ def main():
             done.record(exts[j])
             comm.wait_event(done)
             mine, gath = mines[j][:n * part_px], gathers[j][:n * part_px * world]
-            complete = parallel.collect_parts(mine, gath, args.collective)
+            complete = parallel.collect_parts(mine, gath, args.collective, dst=k % world if args.gather_dst == "rotate" else 0)
             gathered_ev = torch.cuda.Event()
             gathered_ev.record(comm)
             exts[j].wait_event(gathered_ev)  # (every rank: its part buffer is free again only once the exchange has read it)
@@ -443,7 +447,7 @@ def main():
             **({"rehearsal": "all ranks on one GPU, gloo exchange through host memory: not a measurement"} if args.rehearse_on_one_gpu else {}),
             "config": {"workload": "BASELINE configs[2]: Demo 4 bunny.obj (4968 tris, kd-tree) + checker plane + SkyBox sun, "
                                    "1920x1080, MaxRecursion 3, camera (0,0,5)", "rays_per_frame": int(rays_frame),
-                       "partition": f"interleaved 32x8 screen tiles over {world} GPU(s)" + (f", RCCL {args.collective} + device assemble" if gather else ""),
+                       "partition": f"interleaved 32x8 screen tiles over {world} GPU(s)" + (f", RCCL {args.collective}" + (f" (to rank {'k % N' if args.gather_dst == 'rotate' else '0'})" if args.collective == "gather" else "") + " + device assemble" if gather else ""),
                        "frames_per_call": B, "calls_in_flight": F,
                        "single_frame_latency_ms": med(lat), "single_frame_mrays_s": (rays_frame / med(lat) / 1e3) if lat else None,
                        "ms_per_frame_with_d2h": med(d2h), "mrays_s_with_d2h": (rays_frame / med(d2h) / 1e3) if d2h else None,

@@ -2,7 +2,8 @@
 """What ONE rank of an N-GPU run costs per frame, measured on one GPU: renders part 0 of N of config 3 in batches of B
 frames with F batches in flight (render + assemble of a part-major buffer; the RCCL gather itself is not in it).
 Gives the per-rank floor of the strong-scaling bench before an 8-GPU node is available.
-usage: gpu_rank_share.py [N ...]   env RANKSHARE_F=1,2,3  RANKSHARE_B=1,2,4,8  RANKSHARE_K=frames"""
+usage: gpu_rank_share.py [N ...]   env RANKSHARE_F=1,2,3  RANKSHARE_B=1,2,4,8  RANKSHARE_K=frames
+RANKSHARE_ROTATE=1: the rank assembles every N-th call only (bench.py's default, --gather-dst rotate: call k goes to rank k % N)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from raytracing_amd import device, host, scenes
@@ -13,6 +14,7 @@ hs = host.HostScene(sd); desc = hs.flatten(); cam = hs.camera(W, H)
 Fs = [int(f) for f in os.environ.get("RANKSHARE_F", "1,2,3").split(",")]
 Bs = [int(f) for f in os.environ.get("RANKSHARE_B", "1,2,4,8").split(",")]  # 0 = 8 per part (the bench's default)
 K = int(os.environ.get("RANKSHARE_K", "480"))
+ROT = os.environ.get("RANKSHARE_ROTATE", "0") == "1"
 for N in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]:
     prm = device.make_params(W, H, MR, part_index=0, part_count=N, layout=1)
     px = device.part_pixels(prm)
@@ -27,12 +29,13 @@ for N in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]:
             def step(k):
                 j = k % F
                 ctxs[j].render_batch_device(cams, prm, mine[j].data_ptr(), sync=False)
-                ctxs[j].assemble_batch(prm, B, gath[j].data_ptr(), frm[j].data_ptr(), sync=False)
+                if not ROT or k % N == 0:
+                    ctxs[j].assemble_batch(prm, B, gath[j].data_ptr(), frm[j].data_ptr(), sync=False)
             def sync():
                 for c in ctxs: c.synchronize()
             for k in range(4 * F): step(k)
             sync(); t0 = time.perf_counter()
             for k in range(K // B): step(k)
             sync(); dt = (time.perf_counter() - t0) / (K // B * B) * 1e3
-            print(f"parts={N} batch={B} inflight={F}: {dt:.4f} ms/frame  (0.595/N = {0.595 / N:.4f})", flush=True)
+            print(f"parts={N} batch={B} inflight={F}{' assemble every N-th call' if ROT else ''}: {dt:.4f} ms/frame  (0.595/N = {0.595 / N:.4f})", flush=True)
             for c in ctxs: c.close()
