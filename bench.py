@@ -278,7 +278,10 @@ def main():
     # 8 frames per call on one GPU (8 x 2.07 M primary rays = one workspace chunk); a rank's share of a frame shrinks with the
     # rank count, so N GPUs take 8 N frames per call (the library's limit is 64): every rank's launches then carry the rays of
     # 8 whole frames whatever N is
-    B = args.batch if args.batch > 0 else min(device.MAX_BATCH, 8 * world)
+    # ... unless the timed region is shorter than two such calls: a burst of K frames is then traced as two calls of K / 2 in
+    # flight together (the second call's kernels fill the gaps of the first one's latency-bound levels, and its gather overlaps):
+    # 20 frames on a rank's eighth of the tiles take 0.076 ms per frame as one call, 0.070 as two (tools/gpu_rank_share.py)
+    B = args.batch if args.batch > 0 else max(1, min(device.MAX_BATCH, 8 * world, (args.steps + 1) // 2))
     if B > device.MAX_BATCH:
         raise SystemExit(f"--batch {B} > {device.MAX_BATCH}")
     cam_runs = {n: (device.Camera * n)(*([cam] * n)) for n in range(1, B + 1)}
