@@ -106,7 +106,7 @@ enum { ST_KD_NODES = 0, ST_KD_TRIS, ST_KD_LEAVES, ST_KD_POPS, ST_SHAPES, ST_MESH
 
 // Per-frame constants
 struct FrameParams {
-    const rthip_camera *cams;  // device: one per frame of the batch (a plain frame is a batch of one); written by k_clear at the
+    const rthip_camera *cams;  // device: one per frame of the batch (a plain frame is a batch of one); written by k_begin / k_set_cams at the
                                // head of the call's launches (kernel arguments hold 16 cameras, a batch up to RTHIP_MAX_BATCH)
     uint32_t n_frames;
     uint32_t my_tiles;     // tiles of this part in ONE frame: per-part tile ordinal q = frame * my_tiles + tile
@@ -1211,6 +1211,20 @@ __global__ __launch_bounds__(kBlock) void k_set_cams(rthip_camera *dst, uint32_t
     const uint32_t *src = reinterpret_cast<const uint32_t *>(&pack);
     for (uint32_t k = threadIdx.x; k < words; k += kBlock) reinterpret_cast<uint32_t *>(dst)[k] = src[k];
 }
+// the head of a call's launches in ONE kernel: statistics, per-workgroup statistics and list counters cleared, the first 16
+// cameras written (every launch on a frame's chain costs ~4 us of latency, whatever it does)
+__global__ __launch_bounds__(kBlock) void k_begin(uint32_t *a, uint32_t na, uint32_t *b, uint32_t nb, uint32_t *c, uint32_t nc, rthip_camera *dst,
+                                                  uint32_t count, CamPack pack) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < na) a[i] = 0u;
+    if (i < nb) b[i] = 0u;
+    if (i < nc) c[i] = 0u;
+    if (blockIdx.x == 0) {
+        const uint32_t words = count * (uint32_t)(sizeof(rthip_camera) / 4);
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(&pack);
+        for (uint32_t k = threadIdx.x; k < words; k += kBlock) reinterpret_cast<uint32_t *>(dst)[k] = src[k];
+    }
+}
 __global__ __launch_bounds__(kBlock) void k_fill(uint32_t *a, size_t n, uint32_t value) {
     for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) a[i] = value;
 }
@@ -1969,18 +1983,20 @@ static int render_frame(rthip_ctx *c, const rthip_camera *cam, uint32_t n_frames
     uint64_t pixels_done = 0;
     bool interrupted = false;
     auto enqueue = [&]() -> int {
-    for (uint32_t b0 = 0; b0 < n_frames; b0 += kCamsPerLaunch) {  // the call's cameras -> device (a kernel: ordered like the rest)
-        CamPack pack;
-        const uint32_t cnt = n_frames - b0 < kCamsPerLaunch ? n_frames - b0 : kCamsPerLaunch;
-        memcpy(pack.c, cam + b0, sizeof(rthip_camera) * cnt);
-        if (cnt < kCamsPerLaunch) memset(pack.c + cnt, 0, sizeof(rthip_camera) * (kCamsPerLaunch - cnt));
-        hipLaunchKernelGGL(k_set_cams, dim3(1), dim3(kBlock), 0, c->stream, c->d_cams + b0, cnt, pack);
-    }
-    {
-        const uint32_t na = 2 * ST_COUNT, nb = (uint32_t)(2 * 2 * (size_t)bs_stride * levels);
-        const uint32_t most = na > nb ? na : nb;
-        hipLaunchKernelGGL(k_clear, dim3((most + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, (uint32_t *)w.stats, na,
-                           (uint32_t *)w.block_stats, nb, (uint32_t *)nullptr, 0u);
+    {   // statistics, list counters of the first chunk and the first 16 cameras: one launch (k_begin); further cameras 16 per launch
+        const uint32_t na = 2 * ST_COUNT, nb = (uint32_t)(2 * 2 * (size_t)bs_stride * levels), nc = kCounterSlots * kCounterStride;
+        const uint32_t most = na > nb ? (na > nc ? na : nc) : (nb > nc ? nb : nc);
+        for (uint32_t b0 = 0; b0 < n_frames; b0 += kCamsPerLaunch) {  // the call's cameras -> device (a kernel: ordered like the rest)
+            CamPack pack;
+            const uint32_t cnt = n_frames - b0 < kCamsPerLaunch ? n_frames - b0 : kCamsPerLaunch;
+            memcpy(pack.c, cam + b0, sizeof(rthip_camera) * cnt);
+            if (cnt < kCamsPerLaunch) memset(pack.c + cnt, 0, sizeof(rthip_camera) * (kCamsPerLaunch - cnt));
+            if (b0 == 0)
+                hipLaunchKernelGGL(k_begin, dim3((most + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, (uint32_t *)w.stats, na,
+                                   (uint32_t *)w.block_stats, nb, w.counts, nc, c->d_cams, cnt, pack);
+            else
+                hipLaunchKernelGGL(k_set_cams, dim3(1), dim3(kBlock), 0, c->stream, c->d_cams + b0, cnt, pack);
+        }
     }
     auto get_event = [&](hipEvent_t *e) -> int {
         if (ev_used == c->ev_pool.size()) {
@@ -1998,8 +2014,9 @@ static int render_frame(rthip_ctx *c, const rthip_camera *cam, uint32_t n_frames
         fp.n_pix_slots = nq * per_tile;
         fp.N0 = fp.n_pix_slots * spp;
         w.stage_base = (q0 / tiles_per_chunk) * stages_per_chunk + 1;  // (stage 0 = nothing begun yet)
-        hipLaunchKernelGGL(k_clear, dim3((kCounterSlots * kCounterStride + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, w.counts,
-                           kCounterSlots * kCounterStride, (uint32_t *)nullptr, 0u, (uint32_t *)nullptr, 0u);
+        if (q0)  // (the first chunk's were cleared with the statistics)
+            hipLaunchKernelGGL(k_clear, dim3((kCounterSlots * kCounterStride + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, w.counts,
+                               kCounterSlots * kCounterStride, (uint32_t *)nullptr, 0u, (uint32_t *)nullptr, 0u);
         for (uint32_t level = 0; level < levels; level++) {
             uint32_t grid = (fp.N0 + kBlock - 1) / kBlock;
             if (grid > kMaxGridLevel) grid = kMaxGridLevel;  // every level: the kernels stride over their rays (see kMaxGridLevel)
