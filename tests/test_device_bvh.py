@@ -109,6 +109,47 @@ def test_device_built_bvh_of_meshes_of_a_few_triangles(monkeypatch, oracle_lib, 
         assert np.array_equal(host_built[k], want[k]), f"host-built BVH: {k}"
 
 
+@pytest.mark.parametrize("kind", ["identical", "collinear", "flat", "huge", "two_clumps"])
+def test_device_built_bvh_of_degenerate_meshes(monkeypatch, oracle_lib, builder, kind):
+    """inputs that leave a builder without a plane to choose: coincident centroids (split by position all the way down), centroids
+    on one line, a mesh without extent on an axis, coordinates whose box areas overflow fp32, two far clumps of identical triangles"""
+    monkeypatch.setenv("RE_BVH_DEVICE_MIN_TRIS", "1")
+    rng = np.random.default_rng(7)
+    n = 700
+    tri = np.array([[-0.5, -0.4, 0.0], [0.6, -0.3, 0.1], [0.0, 0.7, -0.1]])
+    if kind == "identical":
+        v = np.tile(tri.reshape(1, 9), (n, 1))
+    elif kind == "collinear":
+        v = (tri[None] * 0.2 + np.linspace(-3, 3, n)[:, None, None] * np.array([1.0, 0.5, 0.25])[None, None]).reshape(n, 9)
+    elif kind == "flat":
+        c = rng.uniform(-3, 3, (n, 1, 3)); c[:, :, 2] = 0.0
+        t = tri.copy(); t[:, 2] = 0.0
+        v = (t[None] * 0.3 + c).reshape(n, 9)
+    elif kind == "huge":
+        v = ((tri[None] * 0.4 + rng.uniform(-3, 3, (n, 1, 3))) * 1e25).reshape(n, 9)
+    else:
+        v = np.tile(tri.reshape(1, 9), (n, 1))
+        v[n // 3:] += np.tile([40.0, 0.0, 0.0], 3)
+    sd = scenes.SceneDesc("degenerate mesh: " + kind)
+    sd.camera((0, 0, 9e25 if kind == "huge" else 9))
+    sd.mesh(sd.uniform_material(0xffffff, 0.9), v, np.tile([0.0, 0, 1], (n, 3)), scenes.NORMAL_FACE)
+    sd.ambient_light(0xffffff)
+    sd.color_background(0x102030)
+    hs = host.HostScene(sd)
+    ctx = device.Context(0)
+    try:
+        ctx.upload(hs.flatten())
+        m, nodes, index = ctx.bvh(0)
+        _check_bvh(m, nodes, index, v.reshape(-1, 3, 3))
+        got = ctx.render(hs.camera(96, 64), device.make_params(96, 64, 1), ids=True)
+    finally:
+        ctx.close()
+    want = sd.build(oracle_lib).render(96, 64, max_recursion=1, ids=True, threads=4)
+    assert (want["tri"] >= 0).sum() > 20
+    for k in ("pixels", "shape", "tri"):
+        assert np.array_equal(got[k], want[k]), f"{kind}: {k}"
+
+
 @pytest.mark.parametrize("name", ["cfg3", "cfg3close", "nested", "nested_ssaa"])
 def test_frames_with_device_built_bvhs_match_the_reference_golden(golden, monkeypatch, name):
     """re::HipRaytracer end to end with EVERY mesh's BVH built on the device: the golden frames of the genuine reference"""
