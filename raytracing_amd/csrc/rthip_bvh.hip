@@ -777,6 +777,16 @@ __global__ __launch_bounds__(64) void k_sah_small(const Job *jobs, uint32_t n_jo
         for (int a = 0; a < 3; a++) me.c[a] = centroid[3 * (size_t)me.t + a];
         me.s = 0; me.e = n; me.par = jb.parent; me.side = jb.side;
     }
+    {   // The lanes in the order of their triangle ids: the partition above fills a range in the order its atomics land, and every
+        // tie below (equal centroids, equal costs) goes to the lower lane - with the lanes in a canonical order the subtree is a
+        // function of the SET of triangles, the same from run to run (the splits keep the lanes' relative order).
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < n; j++) rank += ((uint32_t)__builtin_amdgcn_readlane((int)me.t, (int)j) < me.t) ? 1u : 0u;
+        sh[lane < n ? rank : lane] = me;
+        __syncthreads();
+        me = sh[lane];
+        __syncthreads();
+    }
     uint32_t base = lane == 0 ? atomicAdd(&counters[SC_NODES], n - 1u) : 0u;
     base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
     for (uint32_t round = 0; round < 64; round++) {

@@ -77,6 +77,32 @@ def test_device_built_bvh_of_a_height_field_and_of_tiny_meshes(builder):
         ctx.close()
 
 
+def _leaf_sets(nodes, index):
+    ch = nodes["c"]["child"].ravel()
+    leaf = ch[((ch & 0x80000000) != 0) & (ch != 0xffffffff)]
+    first, cnt = leaf & 0x0fffffff, ((leaf >> 28) & 7) + 1
+    return sorted(tuple(sorted(int(t) for t in index[f:f + c])) for f, c in zip(first, cnt))
+
+
+def test_device_sah_tree_is_the_same_from_run_to_run(monkeypatch):
+    """the SAH builder's partition lands in the order of its atomics; the tree must not depend on it (a height field: equal
+    centroid coordinates and equal costs everywhere) - same leaves, same number of nodes, same depth in two builds"""
+    monkeypatch.setenv("RTHIP_BVH_BUILDER", "sah")
+    hs = host.HostScene(scenes.config(4, cells=384)[0])
+    desc = hs.flatten()
+    got = []
+    for _ in range(2):
+        ctx = device.Context(0)
+        try:
+            ctx.upload(desc)
+            m, nodes, index = ctx.bvh(0)
+            got.append((len(nodes), m.bvh_depth, _leaf_sets(nodes, index)))
+        finally:
+            ctx.close()
+    assert got[0][0] == got[1][0] and got[0][1] == got[1][1]
+    assert got[0][2] == got[1][2]
+
+
 @pytest.mark.parametrize("n_tris", [1, 2, 4, 5, 9, 64, 65, 131])
 def test_device_built_bvh_of_meshes_of_a_few_triangles(monkeypatch, oracle_lib, builder, n_tris):
     """(also the regression test of the quad walk's stack size: a BVH that is a lone root pushes up to three children at once;
