@@ -796,23 +796,30 @@ __global__ __launch_bounds__(64) void k_sah_small(const Job *jobs, uint32_t n_jo
         int best_axis = 0;
         uint32_t best_left = 0;
         Box seg_box = empty_box();
-        for (int a = 0; a < 3; a++) {
-            Box L = empty_box(), R = empty_box();
-            uint32_t cl = 0, cr = 0;
-            const float mine = a == 0 ? me.c[0] : (a == 1 ? me.c[1] : me.c[2]);
+        {   // one sweep over the lanes for the three axes (the box of lane j is broadcast once)
+            Box L[3], R[3];
+            uint32_t cl[3] = {0u, 0u, 0u}, cr[3] = {0u, 0u, 0u};
+#pragma unroll
+            for (int a = 0; a < 3; a++) { L[a] = empty_box(); R[a] = empty_box(); }
             for (uint32_t j = 0; j < n; j++) {
-                const float cj = lane_f(a == 0 ? me.c[0] : (a == 1 ? me.c[1] : me.c[2]), j);
+                const float cj[3] = {lane_f(me.c[0], j), lane_f(me.c[1], j), lane_f(me.c[2], j)};
                 Box bj;
 #pragma unroll
                 for (int x = 0; x < 3; x++) { bj.lo[x] = lane_f(me.b.lo[x], j); bj.hi[x] = lane_f(me.b.hi[x], j); }
                 const bool in_seg = j >= me.s && j < me.e;
-                const bool left = cj < mine || (cj == mine && j <= lane);
-                if (in_seg && left) { L = merge(L, bj); cl++; }
-                if (in_seg && !left) { R = merge(R, bj); cr++; }
+#pragma unroll
+                for (int a = 0; a < 3; a++) {
+                    const bool left = cj[a] < me.c[a] || (cj[a] == me.c[a] && j <= lane);
+                    if (in_seg && left) { L[a] = merge(L[a], bj); cl[a]++; }
+                    if (in_seg && !left) { R[a] = merge(R[a], bj); cr[a]++; }
+                }
             }
-            const float cost = cr ? area(L) * (float)((cl + 3u) / 4u) + area(R) * (float)((cr + 3u) / 4u) : 3.0e38f;
-            if (cost < best_cost) { best_cost = cost; best_axis = a; best_left = cl; }
-            seg_box = merge(L, R);  // (whatever the plane: the whole segment)
+#pragma unroll
+            for (int a = 0; a < 3; a++) {
+                const float cost = cr[a] ? area(L[a]) * (float)((cl[a] + 3u) / 4u) + area(R[a]) * (float)((cr[a] + 3u) / 4u) : 3.0e38f;
+                if (cost < best_cost) { best_cost = cost; best_axis = a; best_left = cl[a]; }
+            }
+            seg_box = merge(L[0], R[0]);  // (whatever the plane: the whole segment)
         }
         // the segment's cheapest proposal (lowest lane among equals)
         float wcost = best_cost;
