@@ -1,5 +1,5 @@
 """CPU, world_size 2 over gloo: the multi-GPU framebuffer path (tile-compact buffers of interleaved screen tiles of a
-batch of frames, parallel.collect_parts as bench.py calls it — gather to rank 0 and all-gather —, assemble) with the
+batch of frames, parallel.collect_parts as bench.py calls it — gather to rank 0, to rank 1 and all-gather —, assemble) with the
 per-rank rendering done by the host-compiled core."""
 import ctypes as C
 import os
@@ -42,10 +42,11 @@ def _worker(rank, world, port, w, h, q):
     # frame after frame: what rthip_render_batch_device leaves in HBM
     mine = torch.from_numpy(np.concatenate([parallel.frame_to_part(px, rank, world) for px in frames]).view(np.int32))
     ok = True
-    for how in ("gather", "all_gather"):
+    # bench.py sends call k's parts to rank k % world: both destinations
+    for how, dst in (("gather", 0), ("gather", 1), ("all_gather", 0)):
         gathered = torch.zeros(mine.numel() * world, dtype=torch.int32)
-        complete = parallel.collect_parts(mine, gathered, how)
-        assert complete == (how == "all_gather" or rank == 0)
+        complete = parallel.collect_parts(mine, gathered, how, dst=dst)
+        assert complete == (how == "all_gather" or rank == dst)
         if complete:  # [rank][frame][slot] -> frames: the layout rthip_assemble_batch reads
             g = gathered.numpy().view(np.uint32).reshape(world, n_frames, -1)
             for f in range(n_frames):
