@@ -589,11 +589,15 @@ __device__ __forceinline__ void mesh_closest(const SceneView &sv, const rthip_me
                 tmax = fminf(bvh_tmax_of(dd), t_stop);
             }
         }
-        {   // next pending child (a culled one is dropped by the interior loop)
+        {   // next pending child, two entries at once: after a hit has pulled tmax in, the top of the stack is often culled, and a
+            // culled entry popped alone costs the quad a whole node step (config 4 -0.4 %, a lone config-3 frame -0.7 %; four at
+            // once: config 4 -0.8 %, 8-frame calls of config 3 +0.7 %).  What is still culled is dropped by the interior loop.
             const uint2 top = qs.e[(n ? n : 1u) - 1u];
-            const bool popped_ok = __uint_as_float(top.y) <= tmax;
-            cur = n ? (popped_ok ? top.x : kSkip) : kDone;
-            n = n ? n - 1u : 0u;
+            const uint2 under = qs.e[(n > 1u ? n : 2u) - 2u];
+            const bool ok1 = __uint_as_float(top.y) <= tmax, ok2 = __uint_as_float(under.y) <= tmax;
+            const uint32_t second = n > 1u ? (ok2 ? under.x : kSkip) : kDone;
+            cur = n ? (ok1 ? top.x : second) : kDone;
+            n = n ? (ok1 ? n - 1u : (n > 1u ? n - 2u : 0u)) : 0u;
         }
         }
     }
