@@ -38,6 +38,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 W, H, MAX_REC = 1920, 1080, 3
+FRAME0_CHECKSUM = -27903797358016  # sum of the int32 pixels of the frame from the scene's own camera (unchanged since round 1; its pixels are
+                                   # what tests/test_gpu.py compares with the reference's golden subset)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s peak (spec)
 # fp64 vector peak: 256 CUs x 4 SIMDs x 16 lanes x 2 flops (FMA) x 2.4 GHz = 78.6 TFLOP/s (the guide's 157.3 TFLOP/s
 # fp32 vector figure is twice that through packed fp32).  The kernels are built with -ffp-contract=off (bit parity with the
@@ -217,6 +219,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--repeats", type=int, default=5, help="the timed burst of --steps frames is run this many times; the median is reported")
     ap.add_argument("--inflight", type=int, default=0, help="calls in flight (one context + HIP stream each); 0 = 3")
     ap.add_argument("--batch", type=int, default=0, help="frames traced per call (rthip_render_batch_device: one set of launches for "
                     "the rays of all of them); 0 = 8 per GPU (8, 16, 32, 64 on 1, 2, 4, 8 GPUs; the library's limit is 64)")
@@ -284,7 +287,21 @@ def main():
     B = args.batch if args.batch > 0 else max(1, min(device.MAX_BATCH, 8 * world, (args.steps + 1) // 2))
     if B > device.MAX_BATCH:
         raise SystemExit(f"--batch {B} > {device.MAX_BATCH}")
-    cam_runs = {n: (device.Camera * n)(*([cam] * n)) for n in range(1, B + 1)}
+    # Every frame has a camera of its own: a small orbit around the model (+-0.12 rad about the y axis at the scene's camera
+    # distance, looking at the origin; period 40 frames; frame 0 = the scene's own camera (0,0,5) -> (0,0,-1)).  The cameras are
+    # not part of the launch graph the library replays (they travel through its page-locked camera ring), so this is what the
+    # Sandbox preview's moving camera gets (Sandbox/Sandbox.cpp:315-359).
+    import math
+    PATH = 40
+    dist0 = math.sqrt(sum(x * x for x in sd.camera_pos))
+    path = []
+    for f in range(PATH):
+        th = 0.12 * math.sin(2.0 * math.pi * f / PATH)
+        path.append(hs.camera_at((dist0 * math.sin(th), 0.0, dist0 * math.cos(th)), (0.0 - math.sin(th), 0.0, 0.0 - math.cos(th)), W, H))
+    hs.camera_at(sd.camera_pos, sd.camera_dir, W, H)
+
+    def cam_run(start, n):
+        return (device.Camera * n)(*[path[(start + j) % PATH] for j in range(n)])
 
     # one untimed call on a counting context: ray and BVH-traversal counts of one call of B frames (this rank's share)
     os.environ["RTHIP_COUNTERS"] = "1"
@@ -292,10 +309,15 @@ def main():
     os.environ["RTHIP_COUNTERS"] = "0"
     cctx.upload(desc)
     scratch = torch.zeros(B * (part_px if gather else W * H), dtype=torch.int32, device="cuda")
-    cctx.render_batch_device(cam_runs[B], prm, scratch.data_ptr(), sync=True)
+    cctx.render_batch_device(cam_run(0, B), prm, scratch.data_ptr(), sync=True)
     cst = cctx.stats()
-    aflops = algorithmic_flops(cst)  # per call
-    my_rays = (cst.rays_primary + cst.rays_shadow + cst.rays_reflect) // B  # per frame
+    aflops = algorithmic_flops(cst)  # per call (the first B cameras of the path)
+    path_rays = []                   # this rank's rays of every camera of the path
+    for f in range(PATH):
+        cctx.render_batch_device(cam_run(f, 1), prm, scratch.data_ptr(), sync=True)
+        st1 = cctx.stats()
+        path_rays.append(int(st1.rays_primary + st1.rays_shadow + st1.rays_reflect))
+    my_rays_timed = sum(path_rays[f % PATH] for f in range(args.steps))  # exactly the frames of one timed burst
     cctx.close()
     del scratch
 
@@ -318,11 +340,11 @@ def main():
         exts.append(torch.cuda.ExternalStream(c.stream()))
     comm = torch.cuda.current_stream()
 
-    def call(k, n):
-        """call k: the next n (<= B) frames, on context k % F"""
+    def call(k, n, start=0):
+        """call k: n (<= B) frames, the cameras start .. start + n - 1 of the path, on context k % F"""
         j = k % F
         c = ctxs[j]
-        c.render_batch_device(cam_runs[n], prm, mines[j].data_ptr(), sync=False)
+        c.render_batch_device(cam_run(start, n), prm, mines[j].data_ptr(), sync=False)
         if gather:  # device-side ordering only: render -> RCCL all-gather (torch's stream) -> assemble (context's stream)
             done = torch.cuda.Event()
             done.record(exts[j])
@@ -336,18 +358,21 @@ def main():
                 c.assemble_batch(prm, n, gath.data_ptr(), frames[j].data_ptr(), sync=False)
 
     def run_frames(n_frames):
-        """exactly n_frames frames: calls of B, then one shorter call for the remainder"""
-        k = 0
-        while n_frames > 0:
-            n = min(B, n_frames)
-            call(k, n)
+        """exactly n_frames frames (cameras 0 .. n_frames - 1 of the path): calls of B, then one shorter call for the remainder"""
+        k, f = 0, 0
+        while f < n_frames:
+            n = min(B, n_frames - f)
+            call(k, n, f)
             k += 1
-            n_frames -= n
+            f += n
 
-    def sync_all():
+    def sync_local():
         for c in ctxs:
             c.synchronize()
         torch.cuda.synchronize()
+
+    def sync_all():
+        sync_local()
         if world > 1:
             dist.barrier()
             torch.cuda.synchronize()
@@ -358,11 +383,16 @@ def main():
     if args.steps % B:
         for j in range(3 * F):
             call(j, args.steps % B)
-    sync_all()
-    t0 = time.perf_counter()
-    run_frames(args.steps)
-    sync_all()
-    dt = time.perf_counter() - t0
+    # The timed region: exactly --steps frames between a barrier + synchronize (all ranks start together) and this rank's own
+    # synchronize; the slowest rank's time counts (MAX over ranks below), so no second barrier sits inside the region.
+    # Repeated --repeats times (default 5); `value` is the MEDIAN burst, every sample is in the line.
+    samples = []
+    for _ in range(max(1, args.repeats)):
+        sync_all()
+        t0 = time.perf_counter()
+        run_frames(args.steps)
+        sync_local()
+        samples.append(time.perf_counter() - t0)
 
     # ---- after the timed region -------------------------------------------------------------------------------------
     # (1) per-launch duration of the dominant kernel (HIP events on the contexts' own streams, plain launches instead of the
@@ -378,14 +408,14 @@ def main():
     for c in pctxs:
         c.upload(desc)
     for _ in range(3):
-        pctxs[0].render_batch_device(cam_runs[B], prm, mines[0].data_ptr(), sync=True)
+        pctxs[0].render_batch_device(cam_run(0, B), prm, mines[0].data_ptr(), sync=True)
     st = pctxs[0].stats()
     launch_ms = st.ms_trace / max(1, st.launches_trace)
     over = []
 
     def overlapped(j):
         for _ in range(4):
-            pctxs[j].render_batch_device(cam_runs[B], prm, mines[j].data_ptr(), sync=True)
+            pctxs[j].render_batch_device(cam_run(0, B), prm, mines[j].data_ptr(), sync=True)
             s2 = pctxs[j].stats()
             over.append((s2.ms_trace, s2.launches_trace))
     ths = [threading.Thread(target=overlapped, args=(j,)) for j in range(F)]
@@ -402,12 +432,12 @@ def main():
     lat, d2h = [], []
     cfg4 = None
     if not args.no_extras:
-        for _ in range(3):
-            call(0, 1)
+        for f in range(3):
+            call(0, 1, f)
             sync_all()
-        for _ in range(10):
+        for f in range(3, 3 + 11):   # a lone frame whose camera MOVED since the previous one (the last one is frame 0's camera again)
             t1 = time.perf_counter()
-            call(0, 1)
+            call(0, 1, f if f < 13 else 0)
             sync_all()
             lat.append((time.perf_counter() - t1) * 1e3)
         lat.sort()
@@ -426,18 +456,21 @@ def main():
         c.close()
     if world == 1 and rank == 0 and not args.no_extras and not args.no_config4:
         cfg4 = config4_line(local_rank)
-    total_rays = torch.tensor([float(my_rays), dt], dtype=torch.float64, device="cpu" if args.rehearse_on_one_gpu else "cuda")
+    red_dev = "cpu" if args.rehearse_on_one_gpu else "cuda"
+    rays_t = torch.tensor([float(my_rays_timed), float(path_rays[0])], dtype=torch.float64, device=red_dev)
+    dt_t = torch.tensor(samples, dtype=torch.float64, device=red_dev)
     if world > 1:
-        rays_t = total_rays[:1].clone(); dist.all_reduce(rays_t, op=dist.ReduceOp.SUM)
-        dt_t = total_rays[1:].clone(); dist.all_reduce(dt_t, op=dist.ReduceOp.MAX)
-        rays_frame, dt = float(rays_t.item()), float(dt_t.item())
-    else:
-        rays_frame = float(my_rays)
-    checksum = int(frames[0][:W * H].to(torch.int64).sum().item()) if rank == 0 else 0
+        dist.all_reduce(rays_t, op=dist.ReduceOp.SUM)
+        dist.all_reduce(dt_t, op=dist.ReduceOp.MAX)   # per burst: the slowest rank
+    rays_timed, rays_frame0 = float(rays_t[0].item()), float(rays_t[1].item())  # all ranks: one burst of --steps frames; frame 0 alone
+    samples = sorted(float(x) for x in dt_t.tolist())
+    dt = samples[len(samples) // 2]
+    rays_frame = rays_timed / args.steps
+    checksum = int(frames[0][:W * H].to(torch.int64).sum().item()) if rank == 0 else 0  # the last lone frame: camera 0 of the path
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
-        value = rays_frame * args.steps / dt / 1e6
+        value = rays_timed / dt / 1e6
         n_launch = max(1, st.launches_trace)
         tflops = (aflops / n_launch) / (launch_ms * 1e-3) / 1e12 if launch_ms > 0 else 0.0
         traffic = measured_traffic()
@@ -449,12 +482,17 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             **({"rehearsal": "all ranks on one GPU, gloo exchange through host memory: not a measurement"} if args.rehearse_on_one_gpu else {}),
             "config": {"workload": "BASELINE configs[2]: Demo 4 bunny.obj (4968 tris, kd-tree) + checker plane + SkyBox sun, "
-                                   "1920x1080, MaxRecursion 3, camera (0,0,5)", "rays_per_frame": int(rays_frame),
+                                   "1920x1080, MaxRecursion 3, camera (0,0,5)", "rays_per_frame": rays_frame,
+                       "rays_frame0": int(rays_frame0),
                        "partition": f"interleaved 32x8 screen tiles over {world} GPU(s)" + (f", RCCL {args.collective}" + (f" (to rank {'k % N' if args.gather_dst == 'rotate' else '0'})" if args.collective == "gather" else "") + " + device assemble" if gather else ""),
                        "frames_per_call": B, "calls_in_flight": F,
+                       "camera": f"every frame its own camera: orbit of +-0.12 rad about the y axis, period {PATH} frames, frame 0 = the scene's camera; "
+                                 "one replayed launch graph serves all of them (cameras travel through the library's camera ring)",
+                       "timed_bursts": len(samples), "ms_per_step_samples": [x / args.steps * 1e3 for x in samples],
                        "single_frame_latency_ms": med(lat), "single_frame_mrays_s": (rays_frame / med(lat) / 1e3) if lat else None,
                        "ms_per_frame_with_d2h": med(d2h), "mrays_s_with_d2h": (rays_frame / med(d2h) / 1e3) if d2h else None,
-                       "frame_checksum": checksum},
+                       "frame_checksum": checksum, "frame_checksum_expected": FRAME0_CHECKSUM,
+                       "frame_checksum_ok": (checksum == FRAME0_CHECKSUM) if not args.no_extras else None},
             # The dominant kernel is divergent fp64 / fp32 VALU work over an L2-resident BVH (0.8 MB): its roof is the vector ALU,
             # not HBM.  achieved = algorithmic flops of one launch / its duration when it has the GPU to itself.
             "roofline": {"bound": "valu_fp64", "achieved": tflops, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",

@@ -262,6 +262,9 @@ typedef struct {
     uint32_t rays_redo;          /* rays (all levels, last chunk) re-traced through the reference kd-tree: kd-degenerate rays and exact distance ties */
     uint64_t rays_hard;          /* rays (all levels) that needed a mesh walk = rays traced by the dominant kernel */
     uint64_t shape_tests_easy;   /* RTHIP_COUNTERS=1: shape-table entries tested by k_trace_easy (shape_tests: by the dominant kernel) */
+    /* since the context was created: launch graphs captured (one per frame SHAPE: params, frames per call, output and workspace
+     * pointers, scene - the cameras are not part of it) and calls served by replaying one */
+    uint32_t graphs_captured, graph_replays;
 } rthip_stats;
 
 /* ---- lifecycle ---- */
@@ -322,8 +325,11 @@ int rthip_render_device(rthip_ctx *ctx, const rthip_camera *cam, const rthip_par
  * path is known ahead; also what keeps a GPU busy when its share of a frame is small (part_count > 1). */
 int rthip_render_batch_device(rthip_ctx *ctx, const rthip_camera *cams, uint32_t n_frames, const rthip_params *params,
                               void *d_pixels, int sync);
-/* rthip_render_device for callers that CANNOT ALLOCATE device memory (code under HIP graph capture, tight serving loops,
- * harnesses that forbid hipMalloc).  No counterpart in the reference.  Same frame, same kernels, bit-identical output; the
+/* rthip_render_device for callers that CANNOT ALLOCATE device memory (tight serving loops, harnesses that forbid hipMalloc,
+ * code that must not grow the process's HBM footprint).  No counterpart in the reference.  The call launches on the context's
+ * OWN stream and may synchronise it (when an earlier frame's rthip_interrupt flag has to be lowered: hipStreamSynchronize +
+ * hipMemset of one word) and may call hipFuncSetAttribute for deep trees: it allocates nothing, but it is not itself
+ * capturable into a caller's HIP graph.  Same frame, same kernels, bit-identical output; the
  * per-frame workspace (ray queues, hit / colour records, list counters) lives in a file-scope `static __device__` array of
  * RTHIP_NOALLOC_SCRATCH_BYTES (64 MiB) that every GPU the library runs on holds until the process ends, instead of in
  * hipMalloc'ed buffers, and the call performs no hipMalloc / hipFree / graph instantiation / event creation.  Limits: one
@@ -404,6 +410,9 @@ int rthip_probe_bvh(rthip_ctx *ctx, uint32_t mesh, rthip_mesh *out_mesh, rthip_b
  * 6 (double)(float)a, 7 sin(a), 8 (double)(int)a, 9 fmax(a,b), 10 fmin(a,b) */
 int rthip_probe_arith(rthip_ctx *ctx, int32_t op, uint32_t n, const double *a, const double *b, double *out);
 
+/* diagnostic: number of hipMalloc calls this library has made for scene and frame buffers since it was loaded (all contexts).
+ * tests/test_zz_no_alloc.py checks that rthip_render_device_noalloc leaves it unchanged. */
+uint64_t rthip_debug_device_allocs(void);
 const char *rthip_version(void);
 
 #ifdef __cplusplus

@@ -53,6 +53,7 @@ extern "C" void rthip_set_last_error(const char *msg) { g_err = msg ? msg : ""; 
         if (e_ != hipSuccess) return fail(RTHIP_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
 
+static std::atomic<uint64_t> g_device_allocs{0};  // hipMalloc calls of the frame / scene buffers (rthip_debug_device_allocs)
 struct DevBuf {
     void *p = nullptr;
     size_t bytes = 0;
@@ -62,6 +63,7 @@ struct DevBuf {
         p = nullptr;
         bytes = 0;
         if (n == 0) n = 256;
+        g_device_allocs.fetch_add(1);
         HIP_TRY(hipMalloc(&p, n));
         bytes = n;
         return 0;
@@ -106,8 +108,8 @@ enum { ST_KD_NODES = 0, ST_KD_TRIS, ST_KD_LEAVES, ST_KD_POPS, ST_SHAPES, ST_MESH
 
 // Per-frame constants
 struct FrameParams {
-    const rthip_camera *cams;  // device: one per frame of the batch (a plain frame is a batch of one); written by k_begin / k_set_cams at the
-                               // head of the call's launches (kernel arguments hold 16 cameras, a batch up to RTHIP_MAX_BATCH)
+    const rthip_camera *cams;  // device: one per frame of the batch (a plain frame is a batch of one); written by k_begin at the head of the
+                               // call's launches from the context's page-locked camera ring (a batch holds up to RTHIP_MAX_BATCH)
     uint32_t n_frames;
     uint32_t my_tiles;     // tiles of this part in ONE frame: per-part tile ordinal q = frame * my_tiles + tile
     uint32_t part_slots;   // pixel slots of one frame's tile-compact part buffer (rthip_part_pixels)
@@ -138,6 +140,8 @@ struct __attribute__((aligned(32))) ColRec {
     double r, g, b, refl;  // direct colour (later: folded colour) and the reflectance applied to the child
 };
 static const uint32_t kNoChild = 0xffffffffu;
+static const uint32_t kRedoBlocks = 64;  // workgroups of k_shade that take part in re-tracing the redo list
+static const int32_t kShapeNoRay = -2, kShapeRedo = -3;  // HitSlot::shape: slot outside the image / ray on the redo list (no record yet)
 // Every device counter that workgroups reserve list space from (rays of a level, hard list, redo list) sits in a
 // 256-byte line of its own: returning atomics to ONE line serialise in L2 (~7 ns each), and the spawn and hard-list
 // reservations of a workgroup are in flight together.
@@ -160,6 +164,7 @@ struct Work {
     HitSlot *hit;               // [N] per ray of the current level
     uint32_t *redo;             // [N] rays of the current level that must be re-traced by the full kernel
     uint32_t *redo_count;       // [levels] one counter per level (zeroed with `counts`)
+    uint32_t *redo_stack;       // [stack_cap][kRedoBlocks * kBlock] kd / BVH stacks of the lanes that re-trace the redo list (k_shade)
     uint32_t *hard;             // [N] rays of the current level that need a mesh walk (traced by the quad kernel)
     uint32_t *hard_count;       // [levels]
     PendRec *pend;              // [N] per entry of the hard list
@@ -1111,9 +1116,10 @@ __global__ __launch_bounds__(kBlock, RT_QUAD_OCC) void k_trace_quad(SceneView sv
         const bool done = quad::trace_stage<COUNT>(sv, park, n_shadow, qs, q, live, w, i, analytic, hit_shape, hit_tri, shadow_mask, kc);
         if (!live || q != 0) continue;
         if (COUNT && kc.nodes - nodes_before > max_ray_nodes) max_ray_nodes = kc.nodes - nodes_before;
-        if (!done) {
+        if (!done) {  // -> redo list; its hit slot says so, so that k_shade's pass over the hard list leaves the ray to its redo pass
             const uint32_t slot = atomicAdd(&w.redo_count[0], 1u);
             if (slot < w.N) w.redo[slot] = i;
+            w.hit[i].shape = kShapeRedo;
             continue;
         }
         if (hit_shape < 0) {  // a miss: the whole record
@@ -1140,7 +1146,7 @@ __global__ __launch_bounds__(kBlock, RT_QUAD_OCC) void k_trace_quad(SceneView sv
 // are the latency chain of every sky / marble sample.
 template <bool LIST>
 __global__ __launch_bounds__(kBlock, RT_SHADE_OCC) void k_shade(SceneView sv, FrameParams fp, Work w, uint32_t level, uint32_t n_tables,
-                                                                 uint32_t levels) {
+                                                                 uint32_t levels, uint32_t stack_cap) {
     __shared__ ShadeShared sh;
     const uint32_t n = min(w.N, LIST ? w.hard_count[0] : ((level == 0) ? fp.N0 : level_count(w, level)));
     stage_store(w, w.stage_base + STAGES_PER_LEVEL * level + STAGE_SHADE);
@@ -1158,7 +1164,7 @@ __global__ __launch_bounds__(kBlock, RT_SHADE_OCC) void k_shade(SceneView sv, Fr
         const uint32_t j = base + threadIdx.x;
         uint32_t i = 0;
         HitSlot hs;
-        hs.shape = -2;
+        hs.shape = kShapeNoRay;
         if (j < n) {
             i = LIST ? w.hard[j] : j;
             hs = w.hit[i];
@@ -1170,11 +1176,54 @@ __global__ __launch_bounds__(kBlock, RT_SHADE_OCC) void k_shade(SceneView sv, Fr
         h.local = mk(hs.lx, hs.ly, hs.lz);
         h.normal = mk(hs.nx, hs.ny, hs.nz);
         V3 d = mk(0, 0, 1);
-        if (hs.shape > -2) {
+        const bool have = hs.shape >= -1;  // (not: no ray in the slot, or a ray the redo pass below traces and shades)
+        if (have) {
             const RayRec rr = ray_at(w, level, i);
             d = mk(rr.dx, rr.dy, rr.dz);
         }
-        shade_and_spawn<false>(sv, fp, w, tabs, sh, level, hs.shape > -2, i, h, d, shadow_total, spawn_total);
+        shade_and_spawn<false>(sv, fp, w, tabs, sh, level, have, i, h, d, shadow_total, spawn_total);
+    }
+    // The redo list (rays only the reference kd-tree reproduces: kd-degenerate (ray, mesh) pairs and exact distance ties; normally
+    // empty): re-traced one ray per lane through every query (rtc::trace_stage) and shaded on the spot, by the first workgroups of
+    // this kernel - as a kernel of its own it was four launches of ~5 us on every frame's chain for a list that is almost always
+    // empty.  Stacks in global memory (w.redo_stack): the rare path takes no LDS from the common one.
+    if (LIST) {
+        const uint32_t n_redo = min(w.N, w.redo_count[0]);
+        const uint32_t busy = min(min(gridDim.x, kRedoBlocks), (n + kBlock - 1) / kBlock);  // workgroups that got here and take part
+        if (n_redo && blockIdx.x < busy) {  // (workgroup-uniform)
+            KdStack st = make_stack(w.redo_stack + (size_t)blockIdx.x * kBlock + threadIdx.x, kRedoBlocks * kBlock, stack_cap, nullptr);
+            const uint32_t n_shadow = fp.renderer == RTHIP_RENDER_RAYTRACER ? sv.n_lights : 0u;
+            it = 0;
+            for (uint32_t base = blockIdx.x * kBlock; base < n_redo; base += busy * kBlock) {
+                if ((it++ & (kIrqEvery - 1u)) == 0u) {
+                    if (threadIdx.x == 0) sh.irq = irq_load(w);
+                    __syncthreads();
+                    if (sh.irq) break;
+                }
+                const uint32_t j = base + threadIdx.x;
+                const bool live = j < n_redo;
+                const uint32_t i = live ? w.redo[j] : 0u;
+                V3 o = mk(0, 0, 0), d = mk(0, 0, 1);
+                if (live) {  // (level 0 too: k_trace_easy stored the primary rays it listed)
+                    const RayRec r = ray_at(w, level, i);
+                    o = mk(r.ox, r.oy, r.oz);
+                    d = mk(r.dx, r.dy, r.dz);
+                }
+                HitRec h;
+                h.shape = -1;
+                h.tri = -1;
+                h.shadow_mask = 0;
+                h.local = h.normal = mk(0, 0, 0);
+                st.overflow = false;
+                if (live) trace_stage<false>(sv, o, d, n_shadow, st, h, nullptr);
+                // primary-hit ids come from the un-offset pixel-centre ray (sub-sample 4 of the 3x3 SSAA grid)
+                if (live && level == 0 && w.id_shape && i / fp.n_pix_slots == (fp.aa ? 4u : 0u)) {
+                    w.id_shape[i % fp.n_pix_slots] = h.shape;
+                    w.id_tri[i % fp.n_pix_slots] = h.tri;
+                }
+                shade_and_spawn<false>(sv, fp, w, tabs, sh, level, live, i, h, d, shadow_total, spawn_total);
+            }
+        }
     }
     shade_stats_flush(w, sh, 1, level, levels, shadow_total, spawn_total);
 }
@@ -1218,28 +1267,31 @@ __global__ __launch_bounds__(kBlock) void k_clear(uint32_t *a, uint32_t na, uint
     if (i < nb) b[i] = 0u;
     if (i < nc) c[i] = 0u;
 }
-// the cameras of a call, 16 per launch (kernel arguments), into the context's device camera array
-static const uint32_t kCamsPerLaunch = 16;
-struct CamPack {
-    rthip_camera c[kCamsPerLaunch];
-};
-__global__ __launch_bounds__(kBlock) void k_set_cams(rthip_camera *dst, uint32_t count, CamPack pack) {
-    const uint32_t words = count * (uint32_t)(sizeof(rthip_camera) / 4);
-    const uint32_t *src = reinterpret_cast<const uint32_t *>(&pack);
-    for (uint32_t k = threadIdx.x; k < words; k += kBlock) reinterpret_cast<uint32_t *>(dst)[k] = src[k];
-}
-// the head of a call's launches in ONE kernel: statistics, per-workgroup statistics and list counters cleared, the first 16
-// cameras written (every launch on a frame's chain costs ~4 us of latency, whatever it does)
+// The cameras of a call travel through a RING of slots in page-locked host memory (rthip_ctx::h_cams), not through kernel
+// arguments: a captured graph then holds nothing of the camera, and a caller whose camera moves every frame (the Sandbox
+// preview, Sandbox/Sandbox.cpp:315-359) replays the same graph.  Which slot a call reads is decided on the device: the calls of
+// a context run in stream order, so the k-th k_begin that executes belongs to the k-th call the host enqueued, and k_begin
+// counts them in `seq` (device memory).  The host writes the cameras of call k to slot k % kCamSlots before it enqueues the
+// call (after call k - kCamSlots has finished: an event per slot).  Plain launches pass k explicitly and re-set the counter -
+// should host and device ever disagree, the next plain launch heals it; a replayed graph passes kSeqAuto.
+static const uint32_t kCamSlots = 16;
+static const uint32_t kSeqAuto = 0xffffffffu;
+// the head of a call's launches in ONE kernel: statistics, per-workgroup statistics and list counters cleared, the cameras
+// fetched (every launch on a frame's chain costs ~4 us of latency, whatever it does)
 __global__ __launch_bounds__(kBlock) void k_begin(uint32_t *a, uint32_t na, uint32_t *b, uint32_t nb, uint32_t *c, uint32_t nc, rthip_camera *dst,
-                                                  uint32_t count, CamPack pack) {
+                                                  uint32_t count, const rthip_camera *ring, uint32_t *seq, uint32_t seq_explicit) {
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i < na) a[i] = 0u;
     if (i < nb) b[i] = 0u;
     if (i < nc) c[i] = 0u;
     if (blockIdx.x == 0) {
+        const uint32_t k = seq_explicit != kSeqAuto ? seq_explicit : *seq;  // (every thread reads it before thread 0 advances it)
+        __syncthreads();
         const uint32_t words = count * (uint32_t)(sizeof(rthip_camera) / 4);
-        const uint32_t *src = reinterpret_cast<const uint32_t *>(&pack);
-        for (uint32_t k = threadIdx.x; k < words; k += kBlock) reinterpret_cast<uint32_t *>(dst)[k] = src[k];
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(ring + (size_t)(k % kCamSlots) * RTHIP_MAX_BATCH);
+        for (uint32_t w = threadIdx.x; w < words; w += kBlock)
+            reinterpret_cast<uint32_t *>(dst)[w] = __hip_atomic_load(src + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (threadIdx.x == 0) *seq = k + 1u;
     }
 }
 __global__ __launch_bounds__(kBlock) void k_fill(uint32_t *a, size_t n, uint32_t value) {
@@ -1364,12 +1416,13 @@ struct rthip_ctx {
     SceneView sv;
     bool has_scene = false;
     rthip_scene_desc uploaded{};             // the last uploaded description (its counts; the pointers are the caller's)
-    std::vector<rthip_mesh> mesh_table;      // host copies for rthip_update_scene
+    std::vector<rthip_mesh> mesh_table;      // host copies for rthip_update_scene: the table the DEVICE holds (bvh_* fields rewritten by the upload) ...
+    std::vector<rthip_mesh> mesh_table_in;   // ... and the table as the caller described it (what a later rthip_update_scene brings again)
     std::vector<rthip_bvhnode> mesh_roots;
     std::vector<uint8_t> mesh_device_bvh;    // mesh i's BVH was built on the device (its bvh_* fields in mesh_table are the library's)
     uint32_t stack_cap = 1;
     // frame workspace
-    DevBuf rec, child, rays, counts, stats, block_stats, ids, pixels_tmp, ids_out, hits, redo, pend, probe[8];
+    DevBuf rec, child, rays, counts, stats, block_stats, ids, pixels_tmp, ids_out, hits, redo, redo_stack, pend, probe[8];
     uint32_t bs_stride = 0, bs_levels = 0;
     uint32_t n_tables = 0;
     bool has_meshes = false;
@@ -1379,6 +1432,11 @@ struct rthip_ctx {
     // device-visible side of Interrupt() / Percent (see Work::irq): the flag the kernels poll, and in page-locked host memory
     // the stage word the kernels store to (h_stage[0]) and the request word rthip_interrupt stores to (h_stage[32])
     rthip_camera *d_cams = nullptr;    // RTHIP_MAX_BATCH cameras of the call in flight (all calls of a context run on one stream, in order)
+    rthip_camera *h_cams = nullptr;    // page-locked ring: kCamSlots x RTHIP_MAX_BATCH cameras, slot = call sequence number % kCamSlots (see k_begin)
+    uint32_t *d_cam_seq = nullptr;     // device: calls begun on this context so far
+    uint32_t cam_seq = 0;              // host: calls enqueued on this context so far
+    hipEvent_t cam_ev[16] = {};        // [kCamSlots] recorded behind the call that used the slot
+    uint32_t graphs_captured = 0, graph_replays = 0;
     uint32_t *d_irq = nullptr;
     bool irq_finegrained = false;
     bool irq_dirty = false;            // d_irq may be non-zero (guarded by irq_mutex)
@@ -1391,9 +1449,9 @@ struct rthip_ctx {
     size_t chunk_rays = kMaxLevelRays;
     // one frame = ~20 dependent launches; replaying them as a HIP graph cuts the host cost of a frame from ~80 us to
     // one launch (what bounds small frames and the per-GPU share of a multi-GPU frame).  The graph is re-captured
-    // when anything baked into it changes (camera, params, output pointers, scene, workspace) - but only once the
-    // same key comes twice in a row: a camera that moves every frame (the Sandbox preview) keeps plain launches
-    // instead of paying a capture + instantiation (~1 ms) per frame.
+    // when anything baked into it changes (params, frames per call, output pointers, scene, workspace) - but only once the
+    // same key comes twice in a row (a capture + instantiation costs ~1 ms).  The CAMERAS are not baked in (see k_begin):
+    // a camera that moves every frame (the Sandbox preview) replays one graph.
     bool graphs_enabled = true;
     struct CachedGraph {
         std::vector<unsigned char> key;
@@ -1414,6 +1472,7 @@ static int set_device(rthip_ctx *c) {
 
 extern "C" {
 
+uint64_t rthip_debug_device_allocs(void) { return g_device_allocs.load(); }
 const char *rthip_version(void) { return "raytracing_amd rthip 0.1 (gfx950, fp64, -ffp-contract=off)"; }
 const char *rthip_last_error(void) { return g_err.c_str(); }
 
@@ -1450,6 +1509,11 @@ int rthip_create(int device, rthip_ctx **out) {
     }
     if (e == hipSuccess) e = hipMemset(c->d_irq, 0, 256);
     if (e == hipSuccess) e = hipMalloc((void **)&c->d_cams, sizeof(rthip_camera) * RTHIP_MAX_BATCH);
+    if (e == hipSuccess) e = hipMalloc((void **)&c->d_cam_seq, 256);
+    if (e == hipSuccess) e = hipMemset(c->d_cam_seq, 0, 256);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&c->h_cams, sizeof(rthip_camera) * RTHIP_MAX_BATCH * kCamSlots, hipHostMallocMapped);
+    static_assert(sizeof(((rthip_ctx *)nullptr)->cam_ev) / sizeof(hipEvent_t) == kCamSlots, "one event per camera slot");
+    for (uint32_t k = 0; k < kCamSlots && e == hipSuccess; k++) e = hipEventCreateWithFlags(&c->cam_ev[k], hipEventDisableTiming);
     if (e == hipSuccess) e = hipHostMalloc((void **)&c->h_stage, 256, hipHostMallocMapped);
     if (e == hipSuccess) c->h_stage[0] = c->h_stage[32] = 0;
     if (e == hipSuccess) e = hipEventCreate(&c->ev0);
@@ -1477,13 +1541,16 @@ int rthip_destroy(rthip_ctx *c) {
     (void)hipStreamSynchronize(c->stream);
     DevBuf *all[] = {&c->shapes, &c->meshes, &c->kd_nodes, &c->kd_bounds, &c->kd_refs, &c->tris, &c->tri_normals,
                      &c->materials, &c->noises, &c->perlin, &c->worley, &c->lights, &c->rec, &c->child, &c->rays,
-                     &c->counts, &c->stats, &c->ids, &c->pixels_tmp, &c->ids_out, &c->bvh_nodes, &c->bvh_tris, &c->bvh_index, &c->kd_planes, &c->hits, &c->redo, &c->block_stats, &c->pend};
+                     &c->counts, &c->stats, &c->ids, &c->pixels_tmp, &c->ids_out, &c->bvh_nodes, &c->bvh_tris, &c->bvh_index, &c->kd_planes, &c->hits, &c->redo, &c->redo_stack, &c->block_stats, &c->pend};
     for (DevBuf *b : all) b->release();
     for (DevBuf &b : c->probe) b.release();
     for (auto &g : c->graphs) (void)hipGraphExecDestroy(g.exec);
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->d_irq) (void)hipFree(c->d_irq);
     if (c->d_cams) (void)hipFree(c->d_cams);
+    if (c->d_cam_seq) (void)hipFree(c->d_cam_seq);
+    if (c->h_cams) (void)hipHostFree((void *)c->h_cams);
+    for (hipEvent_t ev : c->cam_ev) if (ev) (void)hipEventDestroy(ev);
     if (c->h_stage) (void)hipHostFree((void *)c->h_stage);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -1520,6 +1587,8 @@ int rthip_interrupt(rthip_ctx *c) {
 }
 int rthip_get_stats(rthip_ctx *c, rthip_stats *out) {
     if (!c || !out) return fail(RTHIP_E_INVALID, "null argument");
+    c->last.graphs_captured = c->graphs_captured;
+    c->last.graph_replays = c->graph_replays;
     *out = c->last;
     return 0;
 }
@@ -1571,6 +1640,14 @@ static int validate_scene(const rthip_scene_desc *s, uint32_t *max_depth, uint32
         if (sp != 1) BAD("material op %u: postfix program leaves %d values", i, sp);
         if (maxsp > RTHIP_MAX_MAT_STACK) return fail(RTHIP_E_UNSUPPORTED, "material op %u: nesting deeper than %d", i, RTHIP_MAX_MAT_STACK);
     }
+    // entries of bvh_tris / bvh_tri_index: n_tris when every mesh brings a BVH; otherwise only the meshes that do have records there
+    uint64_t bvh_tris_total = 0;
+    bool every_mesh_has_bvh = true;
+    for (uint32_t i = 0; i < s->n_meshes; i++) {
+        if (s->meshes[i].bvh_node_count) bvh_tris_total += s->meshes[i].tri_count;
+        else if (s->meshes[i].tri_count) every_mesh_has_bvh = false;
+    }
+    if (every_mesh_has_bvh) bvh_tris_total = s->n_tris;
     for (uint32_t i = 0; i < s->n_meshes; i++) {
         const rthip_mesh &m = s->meshes[i];
         if ((uint64_t)m.node_base + m.node_count > s->n_kd_nodes) BAD("mesh %u: kd nodes out of range", i);
@@ -1597,7 +1674,7 @@ static int validate_scene(const rthip_scene_desc *s, uint32_t *max_depth, uint32
             if ((uint64_t)m.plane_base[a] + m.plane_count[a] > s->n_kd_planes || (m.plane_count[a] && !s->kd_planes)) BAD("mesh %u: kd planes out of range", i);
         if ((uint64_t)m.bvh_node_base + m.bvh_node_count > s->n_bvh_nodes) BAD("mesh %u: bvh nodes out of range", i);
         if (m.bvh_depth > RTHIP_BVH_MAX_DEPTH) BAD("mesh %u: bvh_depth %u", i, m.bvh_depth);
-        if (m.bvh_node_count && (uint64_t)m.bvh_tri_base + m.tri_count > s->n_tris) BAD("mesh %u: bvh triangles out of range", i);
+        if (m.bvh_node_count && (uint64_t)m.bvh_tri_base + m.tri_count > bvh_tris_total) BAD("mesh %u: bvh triangles out of range", i);
         if (m.bvh_depth > *max_bvh_depth) *max_bvh_depth = m.bvh_depth;
         if (!(m.abs_max >= 0.0f)) BAD("mesh %u: abs_max", i);
         for (uint32_t k = 0; k < m.bvh_node_count; k++) {
@@ -1663,14 +1740,14 @@ int rthip_update_scene(rthip_ctx *c, const rthip_scene_desc *s) {
     bool same = s->n_meshes == u.n_meshes && s->n_kd_nodes == u.n_kd_nodes && s->n_kd_refs == u.n_kd_refs && s->n_kd_planes == u.n_kd_planes &&
                 s->n_tris == u.n_tris && s->n_bvh_nodes == u.n_bvh_nodes && !(s->n_meshes && !s->meshes);
     for (uint32_t i = 0; same && i < s->n_meshes; i++) {  // everything but normal_mode (Mesh::NormalMode is read live, Scene.cpp:456) must match
+        // ... the table the caller uploaded (a mixed upload rewrites bvh_tri_base / the bvh_* fields of the meshes whose BVH the
+        // device built: the caller's next description still carries ITS values), or the one the device holds (a caller that
+        // read it back with rthip_probe_bvh)
         rthip_mesh a = s->meshes[i];
-        a.normal_mode = c->mesh_table[i].normal_mode;
-        if (c->mesh_device_bvh[i] && a.bvh_node_count == 0) {  // the BVH this library built at upload: its fields are not the caller's
-            const rthip_mesh &t = c->mesh_table[i];
-            a.bvh_node_base = t.bvh_node_base; a.bvh_node_count = t.bvh_node_count; a.bvh_tri_base = t.bvh_tri_base;
-            a.bvh_depth = t.bvh_depth; a.abs_max = t.abs_max;
-        }
-        same = memcmp(&a, &c->mesh_table[i], sizeof a) == 0 && (s->meshes[i].normal_mode == 0 || s->meshes[i].normal_mode == 1);
+        a.normal_mode = 0;
+        rthip_mesh in = c->mesh_table_in[i], dev = c->mesh_table[i];
+        in.normal_mode = dev.normal_mode = 0;
+        same = (memcmp(&a, &in, sizeof a) == 0 || memcmp(&a, &dev, sizeof a) == 0) && (s->meshes[i].normal_mode == 0 || s->meshes[i].normal_mode == 1);
     }
     if (!same) return fail(RTHIP_E_INVALID, "rthip_update_scene: the mesh table / geometry counts differ from the uploaded scene");
     return upload_scene(c, s, true);
@@ -1690,12 +1767,17 @@ static int upload_scene(rthip_ctx *c, const rthip_scene_desc *s, bool keep_geome
     if (!keep_geometry) {
         // host copies of what an update needs later: the mesh table and every mesh's BVH root
         c->mesh_table.assign(s->meshes, s->meshes + s->n_meshes);
+        c->mesh_table_in = c->mesh_table;
         c->mesh_roots.assign(s->n_meshes, rthip_bvhnode{});
         c->mesh_device_bvh.assign(s->n_meshes, 0);
-        bool any_device = false;
+        // any_device: some mesh gets its BVH built here.  `mixed`: some meshes bring a BVH and others (with triangles) do not -
+        // the caller's bvh_tris / bvh_tri_index then hold only the records of the former (at their bvh_tri_base), so they are
+        // copied mesh by mesh too, never as n_tris records in one piece
+        bool any_device = false, mixed = false;
         for (uint32_t i = 0; i < s->n_meshes; i++) {
             if (s->meshes[i].bvh_node_count) c->mesh_roots[i] = s->bvh_nodes[s->meshes[i].bvh_node_base];
             else if (build_bvh && s->meshes[i].tri_count) any_device = c->mesh_device_bvh[i] = 1;
+            else if (s->meshes[i].tri_count && s->n_bvh_nodes) mixed = true;
         }
         if ((rc = upload(c, c->kd_nodes, s->kd_nodes, sizeof(rthip_kdnode) * s->n_kd_nodes))) return rc;
         if ((rc = upload(c, c->kd_bounds, s->kd_bounds, sizeof(double) * 6 * s->n_kd_nodes))) return rc;
@@ -1703,7 +1785,7 @@ static int upload_scene(rthip_ctx *c, const rthip_scene_desc *s, bool keep_geome
         if ((rc = upload(c, c->tris, s->tris, sizeof(rthip_tri) * s->n_tris))) return rc;
         if ((rc = upload(c, c->tri_normals, s->tri_normals, sizeof(double) * 9 * s->n_tris))) return rc;
         if ((rc = upload(c, c->kd_planes, s->kd_planes, sizeof(double) * s->n_kd_planes))) return rc;
-        if (!any_device) {
+        if (!any_device && !mixed) {
             if ((rc = upload(c, c->bvh_nodes, s->bvh_nodes, sizeof(rthip_bvhnode) * s->n_bvh_nodes))) return rc;
             if ((rc = upload(c, c->bvh_tris, s->bvh_tris, s->n_bvh_nodes ? sizeof(rthip_tri) * s->n_tris : 0))) return rc;
             if ((rc = upload(c, c->bvh_index, s->bvh_tri_index, s->n_bvh_nodes ? sizeof(uint32_t) * s->n_tris : 0))) return rc;
@@ -1900,6 +1982,8 @@ static int render_frame(rthip_ctx *c, const rthip_camera *cam, uint32_t n_frames
         if (c->hits.ensure(sizeof(HitSlot) * N)) return RTHIP_E_HIP;
         if (c->redo.ensure(sizeof(uint32_t) * 2 * N)) return RTHIP_E_HIP;
         if (c->pend.ensure(sizeof(PendRec) * N)) return RTHIP_E_HIP;
+        if (c->redo_stack.ensure(sizeof(uint32_t) * kRedoBlocks * kBlock * (size_t)c->stack_cap_full)) return RTHIP_E_HIP;
+        w.redo_stack = (uint32_t *)c->redo_stack.p;
         w.rec = (ColRec *)c->rec.p;
         w.child = (uint32_t *)c->child.p;
         w.rays = (RayRec *)c->rays.p;
@@ -1933,6 +2017,7 @@ static int render_frame(rthip_ctx *c, const rthip_camera *cam, uint32_t n_frames
         w.hit = (HitSlot *)take(sizeof(HitSlot) * N);
         w.redo = (uint32_t *)take(sizeof(uint32_t) * 2 * N);
         w.pend = (PendRec *)take(sizeof(PendRec) * N);
+        w.redo_stack = (uint32_t *)take(sizeof(uint32_t) * kRedoBlocks * kBlock * (size_t)c->stack_cap_full);
         w.id_shape = w.id_tri = nullptr;
         if (off > RTHIP_NOALLOC_SCRATCH_BYTES)
             return fail(RTHIP_E_UNSUPPORTED, "rthip_render_device_noalloc: %ux%u, max_recursion %u%s needs a %zu-byte workspace, the static scratch "
@@ -1955,9 +2040,7 @@ static int render_frame(rthip_ctx *c, const rthip_camera *cam, uint32_t n_frames
     if (lds_bytes > 160 * 1024) return fail(RTHIP_E_UNSUPPORTED, "kd stack of %u entries does not fit LDS", c->stack_cap);
     if (lds_bytes > 64 * 1024) {
         HIP_TRY(hipFuncSetAttribute((const void *)k_trace<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        HIP_TRY(hipFuncSetAttribute((const void *)k_trace<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
         HIP_TRY(hipFuncSetAttribute((const void *)k_trace<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        HIP_TRY(hipFuncSetAttribute((const void *)k_trace<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     }
     // hot kernel: one short stack per quad (child word + entry parameter per entry); deeper rays overflow into the redo list
     // cannot overflow, see quad::Stack: the deepest node is bvh_depth levels below the root, so a path makes bvh_depth + 1 steps
@@ -1970,6 +2053,20 @@ static int render_frame(rthip_ctx *c, const rthip_camera *cam, uint32_t n_frames
     }
     const size_t lds_tables = (size_t)c->n_tables * 256;
 
+    // ---- the call's cameras -> this call's slot of the page-locked ring (k_begin fetches them; see kCamSlots)
+    auto stage_cams = [&]() -> int {
+        const uint32_t slot = c->cam_seq % kCamSlots;
+        if (c->cam_seq >= kCamSlots) HIP_TRY(hipEventSynchronize(c->cam_ev[slot]));  // the call that last used the slot has finished
+        memcpy(c->h_cams + (size_t)slot * RTHIP_MAX_BATCH, cam, sizeof(rthip_camera) * n_frames);
+        return 0;
+    };
+    auto cams_enqueued = [&]() -> int {  // behind the call's last launch
+        HIP_TRY(hipEventRecord(c->cam_ev[c->cam_seq % kCamSlots], c->stream));
+        c->cam_seq++;
+        return 0;
+    };
+    bool capturing = false;
+
     // ---- what a cached graph depends on
     const bool single_chunk = tiles_per_chunk >= my_tiles;
     const bool profile = c->profile_launches && !noalloc;
@@ -1978,17 +2075,20 @@ static int render_frame(rthip_ctx *c, const rthip_camera *cam, uint32_t n_frames
     if (use_graph) {
         auto put = [&](const void *ptr, size_t n) { key.insert(key.end(), (const unsigned char *)ptr, (const unsigned char *)ptr + n); };
         const void *ptrs[] = {d_pixels, d_shape, d_tri, c->rec.p, c->child.p, c->rays.p, c->counts.p, c->stats.p, c->block_stats.p,
-                              c->ids.p, c->hits.p, c->redo.p, c->pend.p};
-        put(cam, sizeof *cam * n_frames);
+                              c->ids.p, c->hits.p, c->redo.p, c->pend.p, c->redo_stack.p};
+        put(&n_frames, sizeof n_frames);  // (NOT the cameras: they reach the kernels through the camera ring, see k_begin)
         put(p, sizeof *p);
         put(ptrs, sizeof ptrs);
         put(&c->scene_generation, sizeof c->scene_generation);
         put(&c->count_kd, sizeof c->count_kd);
         for (const auto &g : c->graphs) {
             if (g.key != key) continue;
+            if ((rc = stage_cams())) return rc;
             HIP_TRY(hipEventRecord(c->ev0, c->stream));
             HIP_TRY(hipGraphLaunch(g.exec, c->stream));
             HIP_TRY(hipEventRecord(c->ev1, c->stream));
+            if ((rc = cams_enqueued())) return rc;
+            c->graph_replays++;
             c->last.pixels = (uint64_t)my_tiles * per_tile;
             c->last.launches_trace = 0;
             c->last_frames = n_frames;
@@ -2000,20 +2100,12 @@ static int render_frame(rthip_ctx *c, const rthip_camera *cam, uint32_t n_frames
     uint64_t pixels_done = 0;
     bool interrupted = false;
     auto enqueue = [&]() -> int {
-    {   // statistics, list counters of the first chunk and the first 16 cameras: one launch (k_begin); further cameras 16 per launch
+    {   // statistics, list counters of the first chunk, the call's cameras: one launch (k_begin)
         const uint32_t na = 2 * ST_COUNT, nb = (uint32_t)(2 * 2 * (size_t)bs_stride * levels), nc = kCounterSlots * kCounterStride;
         const uint32_t most = na > nb ? (na > nc ? na : nc) : (nb > nc ? nb : nc);
-        for (uint32_t b0 = 0; b0 < n_frames; b0 += kCamsPerLaunch) {  // the call's cameras -> device (a kernel: ordered like the rest)
-            CamPack pack;
-            const uint32_t cnt = n_frames - b0 < kCamsPerLaunch ? n_frames - b0 : kCamsPerLaunch;
-            memcpy(pack.c, cam + b0, sizeof(rthip_camera) * cnt);
-            if (cnt < kCamsPerLaunch) memset(pack.c + cnt, 0, sizeof(rthip_camera) * (kCamsPerLaunch - cnt));
-            if (b0 == 0)
-                hipLaunchKernelGGL(k_begin, dim3((most + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, (uint32_t *)w.stats, na,
-                                   (uint32_t *)w.block_stats, nb, w.counts, nc, c->d_cams, cnt, pack);
-            else
-                hipLaunchKernelGGL(k_set_cams, dim3(1), dim3(kBlock), 0, c->stream, c->d_cams + b0, cnt, pack);
-        }
+        hipLaunchKernelGGL(k_begin, dim3((most + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, (uint32_t *)w.stats, na,
+                           (uint32_t *)w.block_stats, nb, w.counts, nc, c->d_cams, n_frames, (const rthip_camera *)c->h_cams, c->d_cam_seq,
+                           capturing ? kSeqAuto : c->cam_seq);
     }
     auto get_event = [&](hipEvent_t *e) -> int {
         if (ev_used == c->ev_pool.size()) {
@@ -2059,12 +2151,7 @@ static int render_frame(rthip_ctx *c, const rthip_camera *cam, uint32_t n_frames
                         hipLaunchKernelGGL((k_trace_quad<false>), dim3(qgrid), dim3(kBlock), lds_quad, c->stream, c->sv, fp, w, level, quad_cap);
                 }
                 if (profile) HIP_TRY(hipEventRecord(eb, c->stream));
-                if (c->has_meshes) {  // re-trace of the (rare) rays lying exactly in a kd split plane or overflowing the short stack
-                    if (c->count_kd)
-                        hipLaunchKernelGGL((k_trace<true, true>), dim3(64), dim3(kBlock), lds_bytes, c->stream, c->sv, fp, w, level, c->stack_cap);
-                    else
-                        hipLaunchKernelGGL((k_trace<true, false>), dim3(64), dim3(kBlock), lds_bytes, c->stream, c->sv, fp, w, level, c->stack_cap);
-                }
+                // (the redo list - rays lying exactly in a kd split plane, exact distance ties - is re-traced inside k_shade)
             } else {
                 if (profile) HIP_TRY(hipEventRecord(eq, c->stream));
                 if (c->count_kd)
@@ -2075,9 +2162,9 @@ static int render_frame(rthip_ctx *c, const rthip_camera *cam, uint32_t n_frames
             }
             if (p->accel == 0) {
                 if (c->has_meshes)
-                    hipLaunchKernelGGL((k_shade<true>), dim3(grid), dim3(kBlock), lds_tables, c->stream, c->sv, fp, w, level, c->n_tables, levels);
+                    hipLaunchKernelGGL((k_shade<true>), dim3(grid), dim3(kBlock), lds_tables, c->stream, c->sv, fp, w, level, c->n_tables, levels, c->stack_cap);
             } else {
-                hipLaunchKernelGGL((k_shade<false>), dim3(grid), dim3(kBlock), lds_tables, c->stream, c->sv, fp, w, level, c->n_tables, levels);
+                hipLaunchKernelGGL((k_shade<false>), dim3(grid), dim3(kBlock), lds_tables, c->stream, c->sv, fp, w, level, c->n_tables, levels, c->stack_cap);
             }
             if (profile) HIP_TRY(hipEventRecord(ec, c->stream));
         }
@@ -2101,10 +2188,13 @@ static int render_frame(rthip_ctx *c, const rthip_camera *cam, uint32_t n_frames
         }
         hipGraph_t graph = nullptr;
         hipGraphExec_t exec = nullptr;
+        if ((rc = stage_cams())) return rc;
         hipError_t e = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal);
         int erc = 0;
         if (e == hipSuccess) {
+            capturing = true;
             erc = enqueue();
+            capturing = false;
             hipError_t e2 = hipStreamEndCapture(c->stream, &graph);
             if (e2 != hipSuccess) e = e2;
         }
@@ -2118,10 +2208,12 @@ static int render_frame(rthip_ctx *c, const rthip_camera *cam, uint32_t n_frames
         if (graph) (void)hipGraphDestroy(graph);
         if (e == hipSuccess && erc == 0 && exec) {
             c->graphs.push_back({key, exec});
+            c->graphs_captured++;
             c->last_frames = n_frames;
             HIP_TRY(hipEventRecord(c->ev0, c->stream));
             HIP_TRY(hipGraphLaunch(exec, c->stream));
             HIP_TRY(hipEventRecord(c->ev1, c->stream));
+            if ((rc = cams_enqueued())) return rc;
             c->last.pixels = pixels_done;
             c->last.launches_trace = 0;
             return 0;
@@ -2132,10 +2224,12 @@ static int render_frame(rthip_ctx *c, const rthip_camera *cam, uint32_t n_frames
         pixels_done = 0;
     }
     c->last_frames = n_frames;
+    if ((rc = stage_cams())) return rc;
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
     rc = enqueue();
     if (rc) return rc;
     HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    if ((rc = cams_enqueued())) return rc;
     c->last.pixels = pixels_done;
     if (interrupted) {
         HIP_TRY(hipStreamSynchronize(c->stream));
@@ -2227,6 +2321,8 @@ int rthip_collect_stats(rthip_ctx *c, const rthip_params *p, rthip_stats *out) {
     if (set_device(c)) return RTHIP_E_HIP;
     int rc = finish_stats(c, p);
     if (rc) return rc;
+    c->last.graphs_captured = c->graphs_captured;
+    c->last.graph_replays = c->graph_replays;
     if (out) *out = c->last;
     if (c->interrupt.load()) return fail(RTHIP_E_INTERRUPTED, "rthip_render_device: interrupted");
     return 0;
@@ -2356,6 +2452,7 @@ static int probe_out(rthip_ctx *c, void *dst, const void *src, size_t bytes) {
     if (!c) return fail(RTHIP_E_INVALID, "null context");                           \
     if (need_scene && !c->has_scene) return fail(RTHIP_E_STATE, "no scene uploaded"); \
     if (set_device(c)) return RTHIP_E_HIP;                                           \
+    if (need_scene && c->mesh_without_bvh >= 0) c->sv.accel = 1; /* a kd-only mesh: the BVH walk would miss it (render_frame refuses accel = 0 there) */ \
     if (n == 0) return 0;                                                            \
     const uint32_t grid = (n + kBlock - 1) / kBlock;                                 \
     const size_t lds_bytes = (size_t)c->stack_cap * kBlock * sizeof(uint32_t);      \

@@ -891,7 +891,7 @@ __global__ __launch_bounds__(kB) void k_sah_validate(const PNode *bin, const Box
             if (ref >= n_int || ref == id || ref == root) { atomicAdd(&bad[sd], 1u); continue; }
             cb = node_box[ref];
             total += bin[ref].size;
-            if (node_depth[ref] != node_depth[id] + 1u) atomicAdd(&bad[3], 1u);
+            if (node_depth && node_depth[ref] != node_depth[id] + 1u) atomicAdd(&bad[3], 1u);  // (the clustering builder keeps no depths)
         }
         bool inside = true;
         for (int a = 0; a < 3; a++) inside = inside && cb.lo[a] >= me.lo[a] && cb.hi[a] <= me.hi[a];
@@ -1033,6 +1033,20 @@ static int build_nodes(hipStream_t stream, const rthip_tri *d_tris, uint32_t n, 
         if (root_ref & 0x80000000u) {
             snprintf(err, err_len, "BVH build: the clustering left a triangle as the root");
             return RTHIP_E_HIP;
+        }
+        {   // the same check of every link as for the top-down tree, before the plan and collapse kernels walk it
+            uint32_t *bad_d = cnt + 8;
+            BHIP(hipMemsetAsync(bad_d, 0, sizeof(uint32_t) * 8, stream));
+            hipLaunchKernelGGL(k_sah_validate, dim3((n_int + kB - 1) / kB), dim3(kB), 0, stream, bin.as<PNode>(), node_box.as<Box>(), (const uint32_t *)nullptr,
+                               n_int, n, prim_box.as<Box>(), index, root_ref, bad_d);
+            uint32_t bad[8];
+            BHIP(hipMemcpyAsync(bad, bad_d, sizeof bad, hipMemcpyDeviceToHost, stream));
+            BHIP(hipStreamSynchronize(stream));
+            if (root_ref >= n_int || bad[0] || bad[1] || bad[2] || bad[4] || bad[5]) {
+                snprintf(err, err_len, "BVH build: the clustered tree failed its check (root %u of %u; bad left %u right %u size %u box %u finite %u)",
+                         root_ref, n_int, bad[0], bad[1], bad[2], bad[4], bad[5]);
+                return RTHIP_E_UNSUPPORTED;  // (the caller may build this BVH on the host instead)
+            }
         }
         // the collapse plan, bottom-up in the order the clustering made the nodes (a pass only merges clusters of earlier passes)
         {

@@ -21,7 +21,8 @@ SYMBOLS = ["rthip_create", "rthip_destroy", "rthip_last_error", "rthip_upload_sc
            "rthip_part_pixels", "rthip_assemble", "rthip_render_batch_device", "rthip_assemble_batch", "rthip_host_alloc",
            "rthip_host_free", "rthip_update_scene", "rthip_render_device_noalloc", "rthip_collect_stats", "rthip_multi_create",
            "rthip_multi_destroy", "rthip_multi_device_count", "rthip_multi_context", "rthip_multi_transport", "rthip_multi_upload_scene",
-           "rthip_multi_render", "rthip_multi_progress", "rthip_multi_interrupt", "rthip_upload_scene_ex", "rthip_probe_bvh"]
+           "rthip_multi_render", "rthip_multi_progress", "rthip_multi_interrupt", "rthip_upload_scene_ex", "rthip_probe_bvh",
+           "rthip_debug_device_allocs"]
 MAX_BATCH = 64  # RTHIP_MAX_BATCH
 UPLOAD_BUILD_BVH, UPLOAD_KEEP_GEOMETRY = 1, 2  # RTHIP_UPLOAD_*
 
@@ -46,7 +47,8 @@ class Stats(C.Structure):
                 ("wave_steps_max", C.c_uint64), ("wave_tris_max", C.c_uint64), ("wave_steps", C.c_uint64), ("wave_tris", C.c_uint64),
                 ("wave_cycles_max", C.c_uint64), ("fetch_cycles", C.c_uint64),
                 ("level_rays", C.c_uint32 * 17), ("level_ms_trace", C.c_float * 17), ("level_ms_shade", C.c_float * 17), ("level_ms_easy", C.c_float * 17),
-                ("ms_easy", C.c_float), ("rays_redo", C.c_uint32), ("rays_hard", C.c_uint64), ("shape_tests_easy", C.c_uint64)]
+                ("ms_easy", C.c_float), ("rays_redo", C.c_uint32), ("rays_hard", C.c_uint64), ("shape_tests_easy", C.c_uint64),
+                ("graphs_captured", C.c_uint32), ("graph_replays", C.c_uint32)]
 
 
 class Mesh(C.Structure):  # rthip_mesh
@@ -102,6 +104,7 @@ def lib():
     L.rthip_destroy.argtypes = [vp]
     L.rthip_last_error.restype = C.c_char_p
     L.rthip_version.restype = C.c_char_p
+    L.rthip_debug_device_allocs.restype = C.c_uint64
     L.rthip_upload_scene.argtypes = [vp, vp]
     L.rthip_update_scene.argtypes = [vp, vp]
     L.rthip_render.argtypes = [vp, C.POINTER(Camera), C.POINTER(Params), c_u32p, c_i32p, c_i32p]

@@ -92,6 +92,13 @@ class HostScene:
         self.L.rehost_camera(self.h, width, height, fovy, C.byref(cam))
         return cam
 
+    def camera_at(self, pos, direction, width, height, fovy=0.0):
+        """rthip_camera for Scene::Camera = {pos, direction} (the scene keeps that camera, like Sandbox::Update moving it,
+        Sandbox/Sandbox.cpp:315-350); the flattened scene is not touched."""
+        from .sbapi import _vec3
+        self.L.sb_camera(self.h, _vec3(tuple(map(float, pos))), _vec3(tuple(map(float, direction))))
+        return self.camera(width, height, fovy)
+
     def render(self, *a, **kw):
         """HipRaytracer::RenderSync through the sb_render facade."""
         try:

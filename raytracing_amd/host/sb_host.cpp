@@ -51,7 +51,16 @@ static int ensure_device(sb_scene *s) {
     if (rc) return rc;
     if (!s->ctx && (rc = rthip_create(s->device, &s->ctx))) { g_host_err = rthip_last_error(); return rc; }
     if (!s->uploaded) {
-        if ((rc = rthip_upload_scene_ex(s->ctx, &s->flat->desc, UploadFlags(*s->flat)))) { g_host_err = rthip_last_error(); return rc; }
+        rc = rthip_upload_scene_ex(s->ctx, &s->flat->desc, UploadFlags(*s->flat));
+        if (rc == RTHIP_E_UNSUPPORTED && s->flat->needs_device_bvh) {
+            // the device would not build a BVH (deeper than its traversal stacks, failed validation): build them on the host
+            // after all, as HipRaytracer::RenderThread does
+            ForceHostBvhEverywhere(s->scene->GetRoot().get());
+            s->compiled = false;
+            if ((rc = ensure_flat(s))) return rc;
+            rc = rthip_upload_scene_ex(s->ctx, &s->flat->desc, UploadFlags(*s->flat));
+        }
+        if (rc) { g_host_err = rthip_last_error(); return rc; }
         s->uploaded = true;
     }
     return 0;

@@ -55,8 +55,11 @@ def test_bench_line_keeps_the_contract():
     assert d["higher_is_better"] is True and d["vs_baseline"] is None and d["dtype"] == "f64" and d["data"] == "synthetic"
     assert "workload" in d["config"] and "model" not in d["config"]
     # the frame the timed loop rendered is the golden config-3 frame: 4 589 295 rays, and value = rays / time
-    assert d["config"]["rays_per_frame"] == 4589295
-    assert abs(d["value"] - 4589295 / (d["ms_per_step"] * 1e-3) / 1e6) < 1e-6 * d["value"]
+    # (every frame of the timed burst has its own camera; frame 0's is the scene's camera)
+    assert d["config"]["rays_frame0"] == 4589295 and d["config"]["frame_checksum_ok"] is True
+    assert abs(d["config"]["rays_per_frame"] - 4589295) < 0.01 * 4589295
+    assert abs(d["value"] - d["config"]["rays_per_frame"] / (d["ms_per_step"] * 1e-3) / 1e6) < 1e-6 * d["value"]
+    assert d["config"]["timed_bursts"] == 5 and len(d["config"]["ms_per_step_samples"]) == 5
     rf = d["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in rf, k
@@ -84,7 +87,7 @@ def test_bench_multi_rank_control_flow_on_one_gpu():
     """bench.py under torch.distributed.run with two ranks that share GPU 0 and exchange over gloo (RCCL refuses two ranks
     on one device): the N > 1 branch of the script end to end — tile partition, per-rank ray counts summed, gather to
     rank 0, device assemble.  The assembled frame is the single-GPU frame; the throughput it prints is not a measurement."""
-    one = _run_bench("--steps", "8", "--warmup", "8", "--no-cpu-baseline", "--no-extras")
+    one = _run_bench("--steps", "8", "--warmup", "8", "--no-cpu-baseline", "--no-config4", "--repeats", "1")
     assert one.returncode == 0, one.stderr[-2000:]
     ref = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][0])
     # no launcher on the command line: bench.py starts its two ranks itself (the driver's command is `python bench.py --gpus N ...`)
@@ -94,6 +97,6 @@ def test_bench_multi_rank_control_flow_on_one_gpu():
     assert len(lines) == 1, "rank 0 alone prints the line"
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 32 and "rehearsal" in d
-    assert d["config"]["rays_per_frame"] == ref["config"]["rays_per_frame"] == 4589295      # the two parts' rays add up
-    assert d["config"]["frame_checksum"] == ref["config"]["frame_checksum"]                # gathered + assembled = the 1-GPU frame
+    assert d["config"]["rays_frame0"] == ref["config"]["rays_frame0"] == 4589295            # the two parts' rays add up
+    assert d["config"]["frame_checksum"] == ref["config"]["frame_checksum"] and d["config"]["frame_checksum_ok"]  # gathered + assembled = the 1-GPU frame
     assert d["config"]["frames_per_call"] == 16 and "cpu_baseline" not in d   # 8 frames per call and rank

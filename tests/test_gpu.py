@@ -230,6 +230,61 @@ def test_graph_replay_gives_the_same_frames_as_plain_launches(monkeypatch):
     assert all(np.array_equal(out["1"][0][0], out["1"][k][0]) for k in (1, 2, 7)) and np.array_equal(out["1"][4][0], out["1"][6][0])
 
 
+def test_graph_replay_follows_a_moving_camera(monkeypatch):
+    """The cameras are not part of a captured graph (they reach the kernels through the context's page-locked camera ring):
+    a camera that moves every frame - the Sandbox preview, Sandbox/Sandbox.cpp:315-359 - is served by ONE graph, captured at
+    the second frame and replayed from then on; every frame equals the plain-launch render of its camera.  40 asynchronous
+    calls are queued back to back (more than the ring's 16 slots), single frames and batches of 3."""
+    import torch
+    hs = host.HostScene(scenes.config(3, cam_z=2.5)[0])
+    desc = hs.flatten()
+    w, h, n = 160, 96, 40
+    prm = device.make_params(w, h, 3)
+    cams = []
+    for k in range(n):
+        cam = hs.camera(w, h)
+        cam.position[0] = -1.0 + 0.05 * k
+        cam.position[1] = 0.02 * (k % 5)
+        cam.position[2] = 2.4 + 0.01 * k
+        cams.append(cam)
+    monkeypatch.setenv("RTHIP_GRAPH", "0")
+    plain = device.Context(0)
+    plain.upload(desc)
+    want = [plain.render(cam, prm)["pixels"].copy() for cam in cams]
+    plain.close()
+    assert len({x.tobytes() for x in want}) == n
+    monkeypatch.setenv("RTHIP_GRAPH", "1")
+    c = device.Context(0)
+    try:
+        c.upload(desc)
+        # nothing waits between the calls (every call of a graph writes the buffer baked into it: one output buffer, copied out behind each call on the context's stream)
+        ext = torch.cuda.ExternalStream(c.stream())
+        out = torch.zeros(n * w * h, dtype=torch.int32, device="cuda")
+        one = torch.zeros(w * h, dtype=torch.int32, device="cuda")
+        for k in range(n):
+            c.render_device(cams[k], prm, one.data_ptr(), sync=False)
+            with torch.cuda.stream(ext):
+                out[k * w * h:(k + 1) * w * h].copy_(one, non_blocking=True)
+        c.synchronize()
+        torch.cuda.synchronize()
+        got = out.cpu().numpy().view(np.uint32).reshape(n, h, w)
+        for k in range(n):
+            assert np.array_equal(got[k], want[k]), f"frame {k} of the moving camera"
+        st = c.stats()
+        assert st.graphs_captured == 1 and st.graph_replays == n - 2, (st.graphs_captured, st.graph_replays)
+        # batches of 3 cameras: another frame shape, one more graph, replayed for every later run of 3
+        out3 = torch.zeros(3 * w * h, dtype=torch.int32, device="cuda")
+        for k0 in range(0, 12, 3):
+            c.render_batch_device(cams[k0:k0 + 3], prm, out3.data_ptr(), sync=True)
+            got3 = out3.cpu().numpy().view(np.uint32).reshape(3, h, w)
+            for j in range(3):
+                assert np.array_equal(got3[j], want[k0 + j]), f"batch frame {k0 + j}"
+        st = c.stats()
+        assert st.graphs_captured == 2 and st.graph_replays == n - 2 + 2
+    finally:
+        c.close()
+
+
 def test_chunked_frames_are_identical(monkeypatch):
     """frames larger than the per-level workspace are rendered chunk by chunk (8K x SSAA in production); forcing a
     tiny chunk must not change a pixel or a ray count"""

@@ -57,3 +57,42 @@ def test_noalloc_on_a_second_context_of_the_same_gpu_shares_the_array():
     finally:
         a.close()
         b.close()
+
+
+def test_noalloc_first_call_on_a_fresh_context_allocates_nothing():
+    """A context that has never rendered (no workspace of its own exists): the no-allocation entry point must work there and
+    must not create one.  Checked twice: the library's own count of hipMalloc calls stays put across the call, and the free HBM
+    the runtime reports does not shrink by anything like the 60 MB workspace of this frame (a queue's first launches may still
+    make the RUNTIME allocate kernel scratch, hence a bound instead of equality).  Compared with another context's
+    rthip_render_device frame."""
+    sd, _ = scenes.config(3, cam_z=2.5)
+    hs = host.HostScene(sd)
+    w, h, rec = 480, 352, 3   # 168 960 level-0 rays x (36 * 4 + 216) B = 61 MB: almost the whole static array
+    cam, prm = hs.camera(w, h), device.make_params(w, h, rec)
+    ref_ctx, fresh = device.Context(0), device.Context(0)
+    try:
+        ref_ctx.upload(hs.flatten())
+        fresh.upload(hs.flatten())
+        want = torch.zeros(w * h, dtype=torch.int32, device="cuda")
+        got = torch.full((w * h,), 0x5a5a5a5a, dtype=torch.int32, device="cuda")
+        ref_ctx.render_device(cam, prm, want.data_ptr(), sync=True)
+        torch.cuda.synchronize()
+        allocs = device.lib().rthip_debug_device_allocs()
+        free_before = torch.cuda.mem_get_info()[0]
+        fresh.render_device_noalloc(cam, prm, got.data_ptr(), sync=True)
+        free_after = torch.cuda.mem_get_info()[0]
+        assert device.lib().rthip_debug_device_allocs() == allocs, "rthip_render_device_noalloc called hipMalloc"
+        assert free_before - free_after < 40 * 2**20, f"free HBM went from {free_before} to {free_after} across the call"
+        assert len(np.unique(want.cpu().numpy())) > 50
+        assert torch.equal(got, want), f"{int((got != want).sum())} pixels differ from rthip_render_device"
+        # and again, smaller, still without a workspace of its own
+        w2, h2 = 200, 120
+        cam2, prm2 = hs.camera(w2, h2), device.make_params(w2, h2, 2)
+        ref_ctx.render_device(cam2, prm2, want.data_ptr(), sync=True)
+        allocs = device.lib().rthip_debug_device_allocs()
+        fresh.render_device_noalloc(cam2, prm2, got.data_ptr(), sync=True)
+        assert device.lib().rthip_debug_device_allocs() == allocs
+        assert torch.equal(got[:w2 * h2], want[:w2 * h2])
+    finally:
+        ref_ctx.close()
+        fresh.close()
