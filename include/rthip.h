@@ -199,6 +199,9 @@ typedef struct {
     const double *worley_points;        uint64_t n_worley_points;   /* n * 3 doubles */
     const rthip_light *lights;          uint32_t n_lights;
     rthip_background background;
+    /* only read by rthip_upload_scene_ex with RTHIP_UPLOAD_BUILD_KD (may be null otherwise): */
+    const double *tri_verts;            /* n_tris * 9: Triangle::Vertices (three xyz triples) in the order of tris[] */
+    const double *mesh_bounds;          /* n_meshes * 6: Mesh::m_BoundingBox Min xyz, Max xyz as Mesh::Compile leaves it (Scene.cpp:391-406) */
 } rthip_scene_desc;
 
 /* Camera basis of AbstractRaycaster::CreateScreenRay (Raytracer.cpp:102-121), computed once on
@@ -279,14 +282,26 @@ int rthip_upload_scene(rthip_ctx *ctx, const rthip_scene_desc *scene);
 /* rthip_upload_scene with options.
  * RTHIP_UPLOAD_BUILD_BVH: every mesh that has triangles but came without a BVH (bvh_node_count == 0; its bvh_* fields and abs_max
  *   are ignored, and the scene's bvh_tris / bvh_tri_index then hold only the records of the meshes that do bring one, at their
- *   bvh_tri_base) gets its 4-wide BVH built ON THE DEVICE from the triangle records of the upload: Morton codes, radix sort,
- *   binary radix tree, bottom-up boxes, breadth-first collapse to four children with leaves of <= 4 triangles, boxes rounded
- *   outward exactly like the host builder's.  replaces: the acceleration-structure half of Mesh::Compile (Scene.cpp:386-414)
- *   for the structure the frame kernels walk - at 2 M triangles a few milliseconds instead of 0.8 s on 8 host cores and 0.27 GB
- *   less to upload.  The BVH takes no part in a result's arithmetic (see rthip_bvhnode); the kd-tree still comes from the host.
+ *   bvh_tri_base) gets its 4-wide BVH built ON THE DEVICE from the triangle records of the upload (csrc/rthip_bvh.hip): the host
+ *   builder's own algorithm - top-down binned SAH (16 bins per axis over the centroid bounds, cost = area x ceil(count / 4)) down
+ *   to single triangles, level-synchronous above 64 triangles and one wave per subtree below, then the optimal collapse to
+ *   4-wide nodes with leaves of <= 4 triangles; boxes rounded outward exactly like the host builder's; every link checked
+ *   before anything walks the tree (a failed check or a tree deeper than RTHIP_BVH_MAX_DEPTH is RTHIP_E_UNSUPPORTED: build it
+ *   on the host).  replaces: the acceleration-structure half of Mesh::Compile (Scene.cpp:386-414) for the structure the frame
+ *   kernels walk - at 2 M triangles 18 ms of device time (39 ms with the read-backs) instead of 0.45 s on 16 host threads, and
+ *   0.27 GB less to upload.  The BVH takes no part in a result's arithmetic (see rthip_bvhnode).  RTHIP_BVH_BUILDER=ploc
+ *   selects the Morton-order clustering builder kept for comparison.
  * RTHIP_UPLOAD_KEEP_GEOMETRY: rthip_update_scene. */
+/* RTHIP_UPLOAD_BUILD_KD: every mesh that has triangles but came without a kd-tree (node_count == 0; its node_* / ref_* / max_depth /
+ *   plane_* fields are ignored) gets the REFERENCE kd-tree built ON THE DEVICE from scene->tri_verts and scene->mesh_bounds
+ *   (csrc/rthip_kd.hip): KDTreeTriangle's own decisions - depth % 3 axis, split = the mean of the 3n vertex coordinates summed
+ *   sequentially in list order, any-vertex <= / >= membership in list order, the 1.5 n rule, depth cap 100 - level by level with
+ *   all nodes of a level side by side, emitted in the pre-order layout above together with the kd_planes the flattener derives;
+ *   byte-identical to the host builder's arrays.  replaces: KDTreeTriangle::KDTreeTriangle (Scene.cpp:18-95) as called by
+ *   Mesh::Compile (Scene.cpp:386-414).  Without the flag a mesh with triangles and no kd nodes is RTHIP_E_INVALID. */
 #define RTHIP_UPLOAD_BUILD_BVH 1u
 #define RTHIP_UPLOAD_KEEP_GEOMETRY 2u
+#define RTHIP_UPLOAD_BUILD_KD 4u
 int rthip_upload_scene_ex(rthip_ctx *ctx, const rthip_scene_desc *scene, uint32_t flags);
 /* The same for a scene whose MESH GEOMETRY is the one already uploaded: everything is replaced except the mesh
  * arrays (kd_*, tris, tri_normals, bvh_*), whose pointers in `scene` are ignored (may be null); their counts and
@@ -405,6 +420,21 @@ int rthip_probe_raycast(rthip_ctx *ctx, uint32_t max_recursion, uint32_t n, cons
 /* The BVH of mesh `mesh` as the device holds it (test access; matters for BVHs built by RTHIP_UPLOAD_BUILD_BVH): its mesh-table
  * entry, its nodes (room for cap_nodes) and its leaf-order triangle indices (room for cap_tris); null pointers are skipped */
 int rthip_probe_bvh(rthip_ctx *ctx, uint32_t mesh, rthip_mesh *out_mesh, rthip_bvhnode *nodes, uint64_t cap_nodes, uint32_t *tri_index, uint64_t cap_tris);
+/* The kd-tree of mesh `mesh` as the device holds it (test access; matters for trees built by RTHIP_UPLOAD_BUILD_KD): its mesh-table
+ * entry (node_count, ref_count, max_depth, plane_count[]), nodes / bounds (6 doubles per node; room for cap_nodes nodes), leaf
+ * references (room for cap_refs) and the three runs of plane coordinates one after the other (room for cap_planes); null
+ * pointers are skipped */
+int rthip_probe_kd(rthip_ctx *ctx, uint32_t mesh, rthip_mesh *out_mesh, rthip_kdnode *nodes, double *bounds, uint64_t cap_nodes, uint32_t *refs,
+                   uint64_t cap_refs, double *planes, uint64_t cap_planes);
+/* what the last rthip_upload_scene* of this context built on the device */
+typedef struct {
+    uint32_t kd_meshes, kd_nodes, kd_levels, pad;   /* meshes whose kd-tree was built on the device; their nodes; the deepest tree's levels */
+    uint64_t kd_refs;
+    float kd_device_ms;                             /* device time of those builds (events around them) */
+    uint32_t bvh_meshes, bvh_nodes;                 /* meshes whose BVH was built on the device; their nodes */
+    float upload_ms;                                /* host wall time of the whole call */
+} rthip_upload_info;
+int rthip_get_upload_info(rthip_ctx *ctx, rthip_upload_info *out);
 /* IEEE arithmetic self-check of the device (add/mul/div/sqrt/floor/fmodf/casts on n inputs):
  * op 0 a+b, 1 a*b, 2 a/b, 3 sqrt(a), 4 floor(a), 5 (double)fmodf((float)a,(float)b),
  * 6 (double)(float)a, 7 sin(a), 8 (double)(int)a, 9 fmax(a,b), 10 fmin(a,b) */

@@ -353,6 +353,8 @@ struct Flattener {
         d.perlin_tables = out.perlin_tables.data(); d.n_perlin_tables = (uint32_t)(out.perlin_tables.size() / 256);
         d.worley_points = out.worley_points.data(); d.n_worley_points = out.worley_points.size() / 3;
         d.lights = out.lights.data();               d.n_lights = (uint32_t)out.lights.size();
+        d.tri_verts = nullptr;   // (only read by RTHIP_UPLOAD_BUILD_KD: this flattener always brings the kd-tree)
+        d.mesh_bounds = nullptr;
         return 0;
     }
 };

@@ -23,6 +23,7 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -32,6 +33,7 @@
 
 #include "rt_core.hpp"
 #include "rthip_bvh.hpp"
+#include "rthip_kd.hpp"
 
 using namespace rtc;
 
@@ -1420,6 +1422,8 @@ struct rthip_ctx {
     std::vector<rthip_mesh> mesh_table_in;   // ... and the table as the caller described it (what a later rthip_update_scene brings again)
     std::vector<rthip_bvhnode> mesh_roots;
     std::vector<uint8_t> mesh_device_bvh;    // mesh i's BVH was built on the device (its bvh_* fields in mesh_table are the library's)
+    std::vector<uint8_t> mesh_device_kd;     // mesh i's kd-tree was built on the device (its node_* / ref_* / plane_* fields likewise)
+    rthip_upload_info upload_info{};
     uint32_t stack_cap = 1;
     // frame workspace
     DevBuf rec, child, rays, counts, stats, block_stats, ids, pixels_tmp, ids_out, hits, redo, redo_stack, pend, probe[8];
@@ -1595,7 +1599,7 @@ int rthip_get_stats(rthip_ctx *c, rthip_stats *out) {
 
 // ---------------------------------------------------------------------------- scene upload
 // keep_geometry: the mesh arrays are the ones already on the device (rthip_update_scene): only their counts are used
-static int validate_scene(const rthip_scene_desc *s, uint32_t *max_depth, uint32_t *max_bvh_depth, bool keep_geometry) {
+static int validate_scene(const rthip_scene_desc *s, uint32_t *max_depth, uint32_t *max_bvh_depth, bool keep_geometry, bool build_kd) {
 #define BAD(...) return fail(RTHIP_E_INVALID, "rthip_upload_scene: " __VA_ARGS__)
     if (s->n_shapes && !s->shapes) BAD("shapes is null");
     if (s->n_lights && !s->lights) BAD("lights is null");
@@ -1657,6 +1661,10 @@ static int validate_scene(const rthip_scene_desc *s, uint32_t *max_depth, uint32
         if (m.max_depth > *max_depth) *max_depth = m.max_depth;
         if (m.bvh_depth > *max_bvh_depth) *max_bvh_depth = m.bvh_depth;
         if (keep_geometry) continue;  // (the table itself is compared with the uploaded one by the caller)
+        if (m.tri_count && !m.node_count) {  // no kd-tree came with the mesh: the device builds it, if asked to
+            if (!build_kd) BAD("mesh %u has %u triangles and no kd nodes (upload with RTHIP_UPLOAD_BUILD_KD, or supply the tree)", i, m.tri_count);
+            if (!s->tri_verts || !s->mesh_bounds) BAD("mesh %u: RTHIP_UPLOAD_BUILD_KD needs tri_verts and mesh_bounds", i);
+        }
         for (uint32_t k = 0; k < m.node_count; k++) {
             const rthip_kdnode &nd = s->kd_nodes[m.node_base + k];
             if (nd.info & RTHIP_KD_LEAF) {
@@ -1719,7 +1727,7 @@ static int upload(rthip_ctx *c, DevBuf &b, const void *src, size_t bytes) {
     return 0;
 }
 
-static int upload_scene(rthip_ctx *c, const rthip_scene_desc *s, bool keep_geometry, bool build_bvh = false);
+static int upload_scene(rthip_ctx *c, const rthip_scene_desc *s, bool keep_geometry, bool build_bvh = false, bool build_kd = false);
 
 int rthip_upload_scene(rthip_ctx *c, const rthip_scene_desc *s) {
     if (!c || !s) return fail(RTHIP_E_INVALID, "rthip_upload_scene: null argument");
@@ -1728,9 +1736,9 @@ int rthip_upload_scene(rthip_ctx *c, const rthip_scene_desc *s) {
 
 int rthip_upload_scene_ex(rthip_ctx *c, const rthip_scene_desc *s, uint32_t flags) {
     if (!c || !s) return fail(RTHIP_E_INVALID, "rthip_upload_scene_ex: null argument");
-    if (flags & ~(uint32_t)(RTHIP_UPLOAD_BUILD_BVH | RTHIP_UPLOAD_KEEP_GEOMETRY)) return fail(RTHIP_E_INVALID, "rthip_upload_scene_ex: unknown flags 0x%x", flags);
+    if (flags & ~(uint32_t)(RTHIP_UPLOAD_BUILD_BVH | RTHIP_UPLOAD_KEEP_GEOMETRY | RTHIP_UPLOAD_BUILD_KD)) return fail(RTHIP_E_INVALID, "rthip_upload_scene_ex: unknown flags 0x%x", flags);
     if (flags & RTHIP_UPLOAD_KEEP_GEOMETRY) return rthip_update_scene(c, s);
-    return upload_scene(c, s, false, (flags & RTHIP_UPLOAD_BUILD_BVH) != 0);
+    return upload_scene(c, s, false, (flags & RTHIP_UPLOAD_BUILD_BVH) != 0, (flags & RTHIP_UPLOAD_BUILD_KD) != 0);
 }
 
 int rthip_update_scene(rthip_ctx *c, const rthip_scene_desc *s) {
@@ -1753,9 +1761,94 @@ int rthip_update_scene(rthip_ctx *c, const rthip_scene_desc *s) {
     return upload_scene(c, s, true);
 }
 
-static int upload_scene(rthip_ctx *c, const rthip_scene_desc *s, bool keep_geometry, bool build_bvh) {
+static int upload_scene_impl(rthip_ctx *c, const rthip_scene_desc *s, bool keep_geometry, bool build_bvh, bool build_kd);
+static int upload_scene(rthip_ctx *c, const rthip_scene_desc *s, bool keep_geometry, bool build_bvh, bool build_kd) {
+    const auto t0 = std::chrono::steady_clock::now();
+    if (!keep_geometry) c->upload_info = rthip_upload_info{};
+    const int rc = upload_scene_impl(c, s, keep_geometry, build_bvh, build_kd);
+    c->upload_info.upload_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return rc;
+}
+
+// The kd-trees of the meshes that came without one, built on the device (rthip_kd.hip), appended behind the caller's trees in
+// the scene-wide kd arrays; their mesh-table entries are filled in.  Called with the caller's arrays not yet uploaded.
+static int upload_kd_arrays(rthip_ctx *c, const rthip_scene_desc *s, bool any_kd) {
+    int rc;
+    if (!any_kd) {
+        if ((rc = upload(c, c->kd_nodes, s->kd_nodes, sizeof(rthip_kdnode) * s->n_kd_nodes))) return rc;
+        if ((rc = upload(c, c->kd_bounds, s->kd_bounds, sizeof(double) * 6 * s->n_kd_nodes))) return rc;
+        if ((rc = upload(c, c->kd_refs, s->kd_refs, sizeof(uint32_t) * s->n_kd_refs))) return rc;
+        if ((rc = upload(c, c->kd_planes, s->kd_planes, sizeof(double) * s->n_kd_planes))) return rc;
+        return 0;
+    }
+    struct Built { rthip_kdnode *nodes = nullptr; double *bounds = nullptr; uint32_t *refs = nullptr; double *planes = nullptr; rthip_device_kd_info info{}; };
+    std::vector<Built> built(s->n_meshes);
+    DevBuf verts;
+    auto release = [&]() {
+        for (Built &b : built) {
+            if (b.nodes) (void)hipFree(b.nodes);
+            if (b.bounds) (void)hipFree(b.bounds);
+            if (b.refs) (void)hipFree(b.refs);
+            if (b.planes) (void)hipFree(b.planes);
+        }
+        verts.release();
+    };
+    uint64_t n_nodes = s->n_kd_nodes, n_refs = s->n_kd_refs, n_planes = s->n_kd_planes;
+    for (uint32_t i = 0; i < s->n_meshes; i++) {
+        if (!c->mesh_device_kd[i]) continue;
+        const rthip_mesh &m = c->mesh_table[i];
+        if (verts.ensure(sizeof(double) * 9 * (size_t)m.tri_count)) { release(); return RTHIP_E_HIP; }
+        hipError_t e = hipMemcpyAsync(verts.p, s->tri_verts + (size_t)m.tri_base * 9, sizeof(double) * 9 * (size_t)m.tri_count, hipMemcpyHostToDevice, c->stream);
+        if (e != hipSuccess) { release(); return fail(RTHIP_E_HIP, "rthip_upload_scene: %s", hipGetErrorString(e)); }
+        char msg[256] = "";
+        rc = rthip_kd_build_device(c->stream, (const double *)verts.p, m.tri_count, s->mesh_bounds + (size_t)i * 6, &built[i].nodes, &built[i].bounds,
+                                   &built[i].refs, &built[i].planes, &built[i].info, msg, sizeof msg);
+        if (rc) { release(); return fail(rc, "rthip_upload_scene: mesh %u: %s", i, msg); }
+        const rthip_device_kd_info &k = built[i].info;
+        n_nodes += k.n_nodes;
+        n_refs += k.n_refs;
+        n_planes += (uint64_t)k.plane_count[0] + k.plane_count[1] + k.plane_count[2];
+        c->upload_info.kd_meshes++;
+        c->upload_info.kd_nodes += k.n_nodes;
+        c->upload_info.kd_refs += k.n_refs;
+        c->upload_info.kd_device_ms += k.device_ms;
+        if (k.levels > c->upload_info.kd_levels) c->upload_info.kd_levels = k.levels;
+    }
+    if (n_nodes > 0xfffffff0ull || n_refs > 0xfffffff0ull || n_planes > 0xfffffff0ull) { release(); return fail(RTHIP_E_UNSUPPORTED, "rthip_upload_scene: more than 2^32 kd nodes / references"); }
+    if (c->kd_nodes.ensure(sizeof(rthip_kdnode) * n_nodes) || c->kd_bounds.ensure(sizeof(double) * 6 * n_nodes) || c->kd_refs.ensure(sizeof(uint32_t) * n_refs) ||
+        c->kd_planes.ensure(sizeof(double) * n_planes)) { release(); return RTHIP_E_HIP; }
+    hipError_t e = hipSuccess;
+    auto copy = [&](void *dst, const void *src, size_t bytes, hipMemcpyKind kind) { if (e == hipSuccess && bytes) e = hipMemcpyAsync(dst, src, bytes, kind, c->stream); };
+    copy(c->kd_nodes.p, s->kd_nodes, sizeof(rthip_kdnode) * s->n_kd_nodes, hipMemcpyHostToDevice);
+    copy(c->kd_bounds.p, s->kd_bounds, sizeof(double) * 6 * s->n_kd_nodes, hipMemcpyHostToDevice);
+    copy(c->kd_refs.p, s->kd_refs, sizeof(uint32_t) * s->n_kd_refs, hipMemcpyHostToDevice);
+    copy(c->kd_planes.p, s->kd_planes, sizeof(double) * s->n_kd_planes, hipMemcpyHostToDevice);
+    uint64_t nb = s->n_kd_nodes, rb = s->n_kd_refs, pb = s->n_kd_planes;
+    for (uint32_t i = 0; i < s->n_meshes; i++) {
+        if (!c->mesh_device_kd[i]) continue;
+        rthip_mesh &m = c->mesh_table[i];
+        const rthip_device_kd_info &k = built[i].info;
+        copy((rthip_kdnode *)c->kd_nodes.p + nb, built[i].nodes, sizeof(rthip_kdnode) * k.n_nodes, hipMemcpyDeviceToDevice);
+        copy((double *)c->kd_bounds.p + 6 * nb, built[i].bounds, sizeof(double) * 6 * k.n_nodes, hipMemcpyDeviceToDevice);
+        copy((uint32_t *)c->kd_refs.p + rb, built[i].refs, sizeof(uint32_t) * k.n_refs, hipMemcpyDeviceToDevice);
+        const uint64_t np = (uint64_t)k.plane_count[0] + k.plane_count[1] + k.plane_count[2];
+        copy((double *)c->kd_planes.p + pb, built[i].planes, sizeof(double) * np, hipMemcpyDeviceToDevice);
+        m.node_base = (uint32_t)nb; m.node_count = k.n_nodes;
+        m.ref_base = (uint32_t)rb; m.ref_count = k.n_refs;
+        m.max_depth = k.max_depth;
+        uint64_t at = pb;
+        for (int a = 0; a < 3; a++) { m.plane_base[a] = (uint32_t)at; m.plane_count[a] = k.plane_count[a]; at += k.plane_count[a]; }
+        nb += k.n_nodes; rb += k.n_refs; pb += np;
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    release();
+    if (e != hipSuccess) return fail(RTHIP_E_HIP, "rthip_upload_scene: %s", hipGetErrorString(e));
+    return 0;
+}
+
+static int upload_scene_impl(rthip_ctx *c, const rthip_scene_desc *s, bool keep_geometry, bool build_bvh, bool build_kd) {
     uint32_t max_depth = 0, max_bvh_depth = 0;
-    int rc = validate_scene(s, &max_depth, &max_bvh_depth, keep_geometry);
+    int rc = validate_scene(s, &max_depth, &max_bvh_depth, keep_geometry, build_kd);
     if (rc) return rc;
     if (set_device(c)) return RTHIP_E_HIP;
     c->has_scene = false;
@@ -1770,6 +1863,10 @@ static int upload_scene(rthip_ctx *c, const rthip_scene_desc *s, bool keep_geome
         c->mesh_table_in = c->mesh_table;
         c->mesh_roots.assign(s->n_meshes, rthip_bvhnode{});
         c->mesh_device_bvh.assign(s->n_meshes, 0);
+        c->mesh_device_kd.assign(s->n_meshes, 0);
+        bool any_kd = false;
+        for (uint32_t i = 0; i < s->n_meshes; i++)
+            if (build_kd && s->meshes[i].tri_count && !s->meshes[i].node_count) any_kd = c->mesh_device_kd[i] = 1;
         // any_device: some mesh gets its BVH built here.  `mixed`: some meshes bring a BVH and others (with triangles) do not -
         // the caller's bvh_tris / bvh_tri_index then hold only the records of the former (at their bvh_tri_base), so they are
         // copied mesh by mesh too, never as n_tris records in one piece
@@ -1779,12 +1876,9 @@ static int upload_scene(rthip_ctx *c, const rthip_scene_desc *s, bool keep_geome
             else if (build_bvh && s->meshes[i].tri_count) any_device = c->mesh_device_bvh[i] = 1;
             else if (s->meshes[i].tri_count && s->n_bvh_nodes) mixed = true;
         }
-        if ((rc = upload(c, c->kd_nodes, s->kd_nodes, sizeof(rthip_kdnode) * s->n_kd_nodes))) return rc;
-        if ((rc = upload(c, c->kd_bounds, s->kd_bounds, sizeof(double) * 6 * s->n_kd_nodes))) return rc;
-        if ((rc = upload(c, c->kd_refs, s->kd_refs, sizeof(uint32_t) * s->n_kd_refs))) return rc;
+        if ((rc = upload_kd_arrays(c, s, any_kd))) return rc;
         if ((rc = upload(c, c->tris, s->tris, sizeof(rthip_tri) * s->n_tris))) return rc;
         if ((rc = upload(c, c->tri_normals, s->tri_normals, sizeof(double) * 9 * s->n_tris))) return rc;
-        if ((rc = upload(c, c->kd_planes, s->kd_planes, sizeof(double) * s->n_kd_planes))) return rc;
         if (!any_device && !mixed) {
             if ((rc = upload(c, c->bvh_nodes, s->bvh_nodes, sizeof(rthip_bvhnode) * s->n_bvh_nodes))) return rc;
             if ((rc = upload(c, c->bvh_tris, s->bvh_tris, s->n_bvh_nodes ? sizeof(rthip_tri) * s->n_tris : 0))) return rc;
@@ -1817,6 +1911,8 @@ static int upload_scene(rthip_ctx *c, const rthip_scene_desc *s, bool keep_geome
                                             &built[i].info, msg, sizeof msg);
                 if (rc) { release(); return fail(rc, "rthip_upload_scene: mesh %u: %s", i, msg); }
                 total += built[i].info.n_nodes;
+                c->upload_info.bvh_meshes++;
+                c->upload_info.bvh_nodes += built[i].info.n_nodes;
             }
             if (total > 0xfffffff0ull) { release(); return fail(RTHIP_E_UNSUPPORTED, "rthip_upload_scene: more than 2^32 BVH nodes"); }
             if (c->bvh_nodes.ensure(sizeof(rthip_bvhnode) * total)) { release(); return RTHIP_E_HIP; }
@@ -1842,8 +1938,12 @@ static int upload_scene(rthip_ctx *c, const rthip_scene_desc *s, bool keep_geome
         }
         if ((rc = upload(c, c->meshes, c->mesh_table.data(), sizeof(rthip_mesh) * s->n_meshes))) return rc;
     }
-    max_bvh_depth = 0;  // from the table the device holds (it carries the depths of the BVHs built here)
-    for (const rthip_mesh &m : c->mesh_table) max_bvh_depth = m.bvh_depth > max_bvh_depth ? m.bvh_depth : max_bvh_depth;
+    max_bvh_depth = 0;  // from the table the device holds (it carries the depths of the trees built here)
+    max_depth = 0;
+    for (const rthip_mesh &m : c->mesh_table) {
+        max_bvh_depth = m.bvh_depth > max_bvh_depth ? m.bvh_depth : max_bvh_depth;
+        max_depth = m.max_depth > max_depth ? m.max_depth : max_depth;
+    }
     std::vector<rthip_shape> shapes(s->shapes, s->shapes + s->n_shapes);
     for (rthip_shape &sh : shapes) roundtrip_bounds(sh, c->mesh_table.data(), c->mesh_roots.data());
     if ((rc = upload(c, c->shapes, shapes.data(), sizeof(rthip_shape) * s->n_shapes))) return rc;
@@ -2548,6 +2648,37 @@ int rthip_probe_bvh(rthip_ctx *c, uint32_t mesh, rthip_mesh *out_mesh, rthip_bvh
         if (cap_tris < m.tri_count) return fail(RTHIP_E_INVALID, "rthip_probe_bvh: %u triangles, room for %llu", m.tri_count, (unsigned long long)cap_tris);
         if (m.tri_count && m.bvh_node_count) HIP_TRY(hipMemcpy(tri_index, (const uint32_t *)c->bvh_index.p + m.bvh_tri_base, sizeof(uint32_t) * m.tri_count, hipMemcpyDeviceToHost));
     }
+    return 0;
+}
+int rthip_probe_kd(rthip_ctx *c, uint32_t mesh, rthip_mesh *out_mesh, rthip_kdnode *nodes, double *bounds, uint64_t cap_nodes, uint32_t *refs, uint64_t cap_refs,
+                   double *planes, uint64_t cap_planes) {
+    if (!c) return fail(RTHIP_E_INVALID, "null context");
+    if (!c->has_scene) return fail(RTHIP_E_STATE, "no scene uploaded");
+    if (mesh >= c->mesh_table.size()) return fail(RTHIP_E_INVALID, "rthip_probe_kd: mesh %u not in [0,%zu)", mesh, c->mesh_table.size());
+    if (set_device(c)) return RTHIP_E_HIP;
+    const rthip_mesh &m = c->mesh_table[mesh];
+    if (out_mesh) *out_mesh = m;
+    if ((nodes || bounds) && cap_nodes < m.node_count) return fail(RTHIP_E_INVALID, "rthip_probe_kd: %u nodes, room for %llu", m.node_count, (unsigned long long)cap_nodes);
+    if (nodes && m.node_count) HIP_TRY(hipMemcpy(nodes, (const rthip_kdnode *)c->kd_nodes.p + m.node_base, sizeof(rthip_kdnode) * m.node_count, hipMemcpyDeviceToHost));
+    if (bounds && m.node_count) HIP_TRY(hipMemcpy(bounds, (const double *)c->kd_bounds.p + (size_t)6 * m.node_base, sizeof(double) * 6 * m.node_count, hipMemcpyDeviceToHost));
+    if (refs) {
+        if (cap_refs < m.ref_count) return fail(RTHIP_E_INVALID, "rthip_probe_kd: %u references, room for %llu", m.ref_count, (unsigned long long)cap_refs);
+        if (m.ref_count) HIP_TRY(hipMemcpy(refs, (const uint32_t *)c->kd_refs.p + m.ref_base, sizeof(uint32_t) * m.ref_count, hipMemcpyDeviceToHost));
+    }
+    if (planes) {
+        const uint64_t np = (uint64_t)m.plane_count[0] + m.plane_count[1] + m.plane_count[2];
+        if (cap_planes < np) return fail(RTHIP_E_INVALID, "rthip_probe_kd: %llu planes, room for %llu", (unsigned long long)np, (unsigned long long)cap_planes);
+        uint64_t at = 0;
+        for (int a = 0; a < 3; a++) {
+            if (m.plane_count[a]) HIP_TRY(hipMemcpy(planes + at, (const double *)c->kd_planes.p + m.plane_base[a], sizeof(double) * m.plane_count[a], hipMemcpyDeviceToHost));
+            at += m.plane_count[a];
+        }
+    }
+    return 0;
+}
+int rthip_get_upload_info(rthip_ctx *c, rthip_upload_info *out) {
+    if (!c || !out) return fail(RTHIP_E_INVALID, "null argument");
+    *out = c->upload_info;
     return 0;
 }
 int rthip_probe_arith(rthip_ctx *c, int32_t op, uint32_t n, const double *a, const double *b, double *out) {

@@ -22,9 +22,9 @@ SYMBOLS = ["rthip_create", "rthip_destroy", "rthip_last_error", "rthip_upload_sc
            "rthip_host_free", "rthip_update_scene", "rthip_render_device_noalloc", "rthip_collect_stats", "rthip_multi_create",
            "rthip_multi_destroy", "rthip_multi_device_count", "rthip_multi_context", "rthip_multi_transport", "rthip_multi_upload_scene",
            "rthip_multi_render", "rthip_multi_progress", "rthip_multi_interrupt", "rthip_upload_scene_ex", "rthip_probe_bvh",
-           "rthip_debug_device_allocs"]
+           "rthip_debug_device_allocs", "rthip_probe_kd", "rthip_get_upload_info"]
 MAX_BATCH = 64  # RTHIP_MAX_BATCH
-UPLOAD_BUILD_BVH, UPLOAD_KEEP_GEOMETRY = 1, 2  # RTHIP_UPLOAD_*
+UPLOAD_BUILD_BVH, UPLOAD_KEEP_GEOMETRY, UPLOAD_BUILD_KD = 1, 2, 4  # RTHIP_UPLOAD_*
 
 
 class Camera(C.Structure):
@@ -71,7 +71,13 @@ class SceneDesc(C.Structure):  # rthip_scene_desc (tests build variants of a fla
                 ("bvh_nodes", C.c_void_p), ("n_bvh_nodes", C.c_uint64), ("bvh_tris", C.c_void_p), ("bvh_tri_index", C.c_void_p),
                 ("materials", C.c_void_p), ("n_materials", C.c_uint32), ("noises", C.c_void_p), ("n_noises", C.c_uint32),
                 ("perlin_tables", C.c_void_p), ("n_perlin_tables", C.c_uint32), ("worley_points", C.c_void_p), ("n_worley_points", C.c_uint64),
-                ("lights", C.c_void_p), ("n_lights", C.c_uint32), ("background", Background)]
+                ("lights", C.c_void_p), ("n_lights", C.c_uint32), ("background", Background),
+                ("tri_verts", C.c_void_p), ("mesh_bounds", C.c_void_p)]
+
+
+class UploadInfo(C.Structure):  # rthip_upload_info
+    _fields_ = [("kd_meshes", C.c_uint32), ("kd_nodes", C.c_uint32), ("kd_levels", C.c_uint32), ("pad", C.c_uint32), ("kd_refs", C.c_uint64),
+                ("kd_device_ms", C.c_float), ("bvh_meshes", C.c_uint32), ("bvh_nodes", C.c_uint32), ("upload_ms", C.c_float)]
 
 
 class RthipError(RuntimeError):
@@ -112,6 +118,8 @@ def lib():
     L.rthip_render_device_noalloc.argtypes = [vp, C.POINTER(Camera), C.POINTER(Params), vp, C.c_int]
     L.rthip_upload_scene_ex.argtypes = [vp, vp, C.c_uint32]
     L.rthip_probe_bvh.argtypes = [vp, C.c_uint32, C.POINTER(Mesh), vp, C.c_uint64, vp, C.c_uint64]
+    L.rthip_probe_kd.argtypes = [vp, C.c_uint32, C.POINTER(Mesh), vp, vp, C.c_uint64, vp, C.c_uint64, vp, C.c_uint64]
+    L.rthip_get_upload_info.argtypes = [vp, C.POINTER(UploadInfo)]
     L.rthip_collect_stats.argtypes = [vp, C.POINTER(Params), C.POINTER(Stats)]
     L.rthip_multi_create.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(vp)]
     L.rthip_multi_destroy.argtypes = [vp]
@@ -185,10 +193,29 @@ class Context:
         except Exception:
             pass
 
-    def upload(self, desc_ptr, build_bvh=True):
-        """desc_ptr: `const rthip_scene_desc*` (e.g. from host.HostScene.flatten()).  build_bvh: meshes that come without a BVH
-        (the host library leaves the big ones to the device) get theirs built on the device (RTHIP_UPLOAD_BUILD_BVH)."""
-        self._check(self.L.rthip_upload_scene_ex(self.h, desc_ptr, UPLOAD_BUILD_BVH if build_bvh else 0))
+    def upload(self, desc_ptr, build_bvh=True, build_kd=True):
+        """desc_ptr: `const rthip_scene_desc*` (e.g. from host.HostScene.flatten()).  build_bvh / build_kd: meshes that come without
+        a BVH / without their kd-tree (the host library leaves the big ones to the device) get them built on the device
+        (RTHIP_UPLOAD_BUILD_BVH / RTHIP_UPLOAD_BUILD_KD)."""
+        self._check(self.L.rthip_upload_scene_ex(self.h, desc_ptr, (UPLOAD_BUILD_BVH if build_bvh else 0) | (UPLOAD_BUILD_KD if build_kd else 0)))
+
+    def upload_info(self):
+        u = UploadInfo()
+        self._check(self.L.rthip_get_upload_info(self.h, C.byref(u)))
+        return u
+
+    def kd(self, mesh=0):
+        """the kd-tree of a mesh as the device holds it: (mesh-table entry, nodes as a structured array [split, link, info], bounds [n, 6],
+        refs, planes = the three axes' runs one after the other)"""
+        m = Mesh()
+        self._check(self.L.rthip_probe_kd(self.h, mesh, C.byref(m), None, None, 0, None, 0, None, 0))
+        nodes = np.zeros(m.node_count, dtype=np.dtype([("split", "<f8"), ("link", "<u4"), ("info", "<u4")]))
+        bounds = np.zeros((m.node_count, 6))
+        refs = np.zeros(m.ref_count, np.uint32)
+        planes = np.zeros(sum(m.plane_count), np.float64)
+        vp = lambda a: a.ctypes.data_as(C.c_void_p)
+        self._check(self.L.rthip_probe_kd(self.h, mesh, None, vp(nodes), vp(bounds), len(nodes), vp(refs), len(refs), vp(planes), len(planes)))
+        return m, nodes, bounds, refs, planes
 
     def bvh(self, mesh=0):
         """(mesh-table entry, nodes as a structured array [n]['c'][4], leaf-order triangle indices) of a mesh's BVH on the device"""

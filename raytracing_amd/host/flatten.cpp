@@ -150,7 +150,14 @@ struct Flattener {
         }
         const KdTreeFlat &kd = mesh->GetKdTree();
         const auto &tris = mesh->GetTriangles();
-        if (kd.nodes.empty()) return Unsupported("Mesh was not compiled");
+        const bool device_kd = mesh->KdBuiltOnDevice() && kd.nodes.empty() && !tris.empty();  // left to RTHIP_UPLOAD_BUILD_KD
+        if (device_kd) out.needs_device_kd = true;
+        if (kd.nodes.empty() && !device_kd) return Unsupported("Mesh was not compiled");
+        {
+            const BoundingBox &bb = mesh->GetBounds();
+            const double b6[6] = {bb.Min.X, bb.Min.Y, bb.Min.Z, bb.Max.X, bb.Max.Y, bb.Max.Z};
+            out.mesh_bounds.insert(out.mesh_bounds.end(), b6, b6 + 6);
+        }
         rthip_mesh m;
         std::memset(&m, 0, sizeof m);
         m.node_base = (uint32_t)out.kd_nodes.size();
@@ -172,7 +179,7 @@ struct Flattener {
         out.kd_refs.insert(out.kd_refs.end(), kd.refs.begin(), kd.refs.end());
         std::vector<double> axis_planes[3];
         std::future<void> sorted[3];
-        for (unsigned a = 0; a < 3; a++)  // plane coordinates of every kd box on axis a
+        for (unsigned a = 0; a < 3 && !device_kd; a++)  // plane coordinates of every kd box on axis a
             sorted[a] = std::async(std::launch::async, [&, a] {
                 std::vector<double> &planes = axis_planes[a];
                 planes = {kd.bounds[a], kd.bounds[3 + a]};
@@ -181,7 +188,7 @@ struct Flattener {
                 std::sort(planes.begin(), planes.end());
                 planes.erase(std::unique(planes.begin(), planes.end()), planes.end());
             });
-        for (unsigned a = 0; a < 3; a++) {
+        for (unsigned a = 0; a < 3 && !device_kd; a++) {
             sorted[a].get();
             const std::vector<double> &planes = axis_planes[a];
             m.plane_base[a] = (uint32_t)out.kd_planes.size();
@@ -219,6 +226,7 @@ struct Flattener {
         }
         out.tris.resize(t0 + n);
         out.tri_normals.resize(9 * (t0 + n));
+        if (device_kd) out.tri_verts.resize(9 * (t0 + n));  // (zeros for the meshes in front that bring their tree)
         ParallelSlices(n, [&](size_t i0, size_t i1) {
             for (size_t i = i0; i < i1; i++) {
                 if (!device_bvh) {
@@ -230,6 +238,10 @@ struct Flattener {
                 out.tris[t0 + i] = pack(t);
                 double *nn = &out.tri_normals[9 * (t0 + i)];
                 for (int k = 0; k < 3; k++) Put(nn + 3 * k, t.Normals[k]);
+                if (device_kd) {
+                    double *vv = &out.tri_verts[9 * (t0 + i)];
+                    for (int k = 0; k < 3; k++) Put(vv + 3 * k, t.Vertices[k]);
+                }
             }
         });
         idx = (int32_t)out.meshes.size();
@@ -338,10 +350,20 @@ struct Flattener {
         d.perlin_tables = out.perlin_tables.data(); d.n_perlin_tables = (uint32_t)(out.perlin_tables.size() / 256);
         d.worley_points = out.worley_points.data(); d.n_worley_points = out.worley_points.size() / 3;
         d.lights = out.lights.data();               d.n_lights = (uint32_t)out.lights.size();
+        d.tri_verts = nullptr;
+        d.mesh_bounds = nullptr;
+        if (out.needs_device_kd) {
+            out.tri_verts.resize(9 * out.tris.size());
+            d.tri_verts = out.tri_verts.data();
+            d.mesh_bounds = out.mesh_bounds.data();
+        }
         if (previous) {
             if (out.meshes.size() != previous->meshes.size()) return kGeometryChanged;
             out.geometry_kept = true;
             out.needs_device_bvh = previous->needs_device_bvh;
+            out.needs_device_kd = previous->needs_device_kd;
+            d.tri_verts = nullptr;
+            d.mesh_bounds = nullptr;
             const rthip_scene_desc &pd = previous->desc;
             d.kd_nodes = nullptr; d.kd_bounds = nullptr; d.kd_refs = nullptr; d.kd_planes = nullptr; d.tris = nullptr;
             d.tri_normals = nullptr; d.bvh_nodes = nullptr; d.bvh_tris = nullptr; d.bvh_tri_index = nullptr;
@@ -370,7 +392,10 @@ int FlattenScene(Scene *scene, FlatScene &out, std::string &error, const FlatSce
 
 void ForceHostBvhEverywhere(SceneNode *node) {
     if (auto shape = node->GetComponentOfType<Shape>())
-        if (auto mesh = dynamic_cast<Mesh *>(shape.get())) mesh->BuildHostBvh();
+        if (auto mesh = dynamic_cast<Mesh *>(shape.get())) {
+            mesh->BuildHostBvh();
+            mesh->BuildHostKd();
+        }
     for (auto &child : node->GetChildren()) ForceHostBvhEverywhere(child.get());
 }
 
@@ -384,9 +409,10 @@ void FlatScene::ReleaseGeometry() {
     std::vector<rthip_bvhnode>().swap(bvh_nodes);
     std::vector<rthip_tri>().swap(bvh_tris);
     std::vector<uint32_t>().swap(bvh_tri_index);
+    std::vector<double>().swap(tri_verts);
     rthip_scene_desc &d = desc;  // counts stay: they describe what the device holds
     d.kd_nodes = nullptr; d.kd_bounds = nullptr; d.kd_refs = nullptr; d.kd_planes = nullptr; d.tris = nullptr;
-    d.tri_normals = nullptr; d.bvh_nodes = nullptr; d.bvh_tris = nullptr; d.bvh_tri_index = nullptr;
+    d.tri_normals = nullptr; d.bvh_nodes = nullptr; d.bvh_tris = nullptr; d.bvh_tri_index = nullptr; d.tri_verts = nullptr;
 }
 
 void MakeCamera(const Scene *scene, size_t width, size_t height, real fovY, rthip_camera &cam) {

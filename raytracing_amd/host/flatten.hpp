@@ -21,6 +21,8 @@ struct FlatScene {
     std::vector<rthip_bvhnode> bvh_nodes;
     std::vector<rthip_tri> bvh_tris;
     std::vector<uint32_t> bvh_tri_index;
+    std::vector<double> tri_verts;    // 9 per triangle, only when needs_device_kd
+    std::vector<double> mesh_bounds;  // 6 per mesh
     std::vector<rthip_matop> materials;
     std::vector<rthip_noise> noises;
     std::vector<uint8_t> perlin_tables;
@@ -31,6 +33,7 @@ struct FlatScene {
     // (mesh, Mesh::GetRevision()) in meshes[] order: identifies the geometry arrays above
     std::vector<std::pair<const Mesh *, uint64_t>> mesh_signature;
     bool needs_device_bvh = false;  // some mesh comes without a BVH: upload with RTHIP_UPLOAD_BUILD_BVH (see Mesh::BvhBuiltOnDevice)
+    bool needs_device_kd = false;   // some mesh comes without its kd-tree: upload with RTHIP_UPLOAD_BUILD_KD (see Mesh::KdBuiltOnDevice)
     bool geometry_kept = false;  // flattened against `previous`: geometry arrays empty, desc pointers null, counts kept
 
     // drops the geometry arrays (they can be hundreds of MB) but keeps what a later FlattenScene(..., this) needs
@@ -47,9 +50,9 @@ int FlattenScene(Scene *scene, FlatScene &out, std::string &error, const FlatSce
 // Camera basis of AbstractRaycaster::CreateScreenRay (Raytracer.cpp:102-110) computed once per frame.
 // upload flags (rthip_upload_scene_ex) that go with a flattened scene
 inline uint32_t UploadFlags(const FlatScene &f) {
-    return f.geometry_kept ? RTHIP_UPLOAD_KEEP_GEOMETRY : (f.needs_device_bvh ? RTHIP_UPLOAD_BUILD_BVH : 0u);
+    return f.geometry_kept ? RTHIP_UPLOAD_KEEP_GEOMETRY : ((f.needs_device_bvh ? RTHIP_UPLOAD_BUILD_BVH : 0u) | (f.needs_device_kd ? RTHIP_UPLOAD_BUILD_KD : 0u));
 }
-// every mesh below `node` gets a host-built BVH from now on (after the device refused to build one: deeper than its stacks)
+// every mesh below `node` gets a host-built BVH and kd-tree from now on (after the device refused to build one: deeper than its stacks, ...)
 void ForceHostBvhEverywhere(SceneNode *node);
 
 void MakeCamera(const Scene *scene, size_t width, size_t height, real fovY, rthip_camera &cam);

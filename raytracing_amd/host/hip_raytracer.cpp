@@ -135,7 +135,7 @@ void HipRaytracer::RenderThread(Scene *scene, std::promise<RenderStatus> p) {
         if (!rc) {
             auto upload = [&]() { return m_Multi ? rthip_multi_upload_scene(m_Multi, &flat.desc, UploadFlags(flat)) : rthip_upload_scene_ex(m_Ctx, &flat.desc, UploadFlags(flat)); };
             rc = upload();
-            if (rc == RTHIP_E_UNSUPPORTED && flat.needs_device_bvh && !flat.geometry_kept) {
+            if (rc == RTHIP_E_UNSUPPORTED && (flat.needs_device_bvh || flat.needs_device_kd) && !flat.geometry_kept) {
                 // the device would not build a BVH (deeper than its traversal stacks): build them on the host after all
                 ForceHostBvhEverywhere(scene->GetRoot().get());
                 flat = FlatScene();

@@ -219,11 +219,19 @@ public:
     bool BvhBuiltOnDevice() const;
     void BuildHostBvh();
     static size_t DeviceBvhMinTriangles();
+    // additive, likewise for the kd-tree: meshes of at least DeviceKdMinTriangles() triangles (2^18; env RE_KD_DEVICE_MIN_TRIS,
+    // 0 = never) leave KDTreeTriangle's build (Scene.cpp:18-95) to the device (RTHIP_UPLOAD_BUILD_KD, csrc/rthip_kd.hip: the same
+    // splits, byte-identical arrays); GetKdTree() is then empty.  ForceHostKd / BuildHostKd() bring the host build back.
+    bool ForceHostKd = false;
+    bool KdBuiltOnDevice() const;
+    void BuildHostKd();
+    static size_t DeviceKdMinTriangles();
     const BoundingBox &GetBounds() const { return m_BoundingBox; }              // additive
     // additive: changes every time Compile() rebuilds the acceleration structures (process-wide unique), so a renderer
     // can tell that the geometry it has already flattened and uploaded is still the current one
     uint64_t GetRevision() const { return m_Revision; }
 private:
+    void BuildKdTree();
     bool m_Invalidated = true;
     uint64_t m_Revision = 0;
     KdTreeFlat m_KdTree;

@@ -52,7 +52,7 @@ static int ensure_device(sb_scene *s) {
     if (!s->ctx && (rc = rthip_create(s->device, &s->ctx))) { g_host_err = rthip_last_error(); return rc; }
     if (!s->uploaded) {
         rc = rthip_upload_scene_ex(s->ctx, &s->flat->desc, UploadFlags(*s->flat));
-        if (rc == RTHIP_E_UNSUPPORTED && s->flat->needs_device_bvh) {
+        if (rc == RTHIP_E_UNSUPPORTED && (s->flat->needs_device_bvh || s->flat->needs_device_kd)) {
             // the device would not build a BVH (deeper than its traversal stacks, failed validation): build them on the host
             // after all, as HipRaytracer::RenderThread does
             ForceHostBvhEverywhere(s->scene->GetRoot().get());

@@ -128,6 +128,31 @@ void Mesh::BuildHostBvh() {
     m_Revision = ++late;  // the flattened geometry changes: a renderer must not keep what it uploaded
 }
 
+size_t Mesh::DeviceKdMinTriangles() {
+    if (const char *e = std::getenv("RE_KD_DEVICE_MIN_TRIS")) {
+        const long long v = atoll(e);
+        return v <= 0 ? (size_t)-1 : (size_t)v;
+    }
+    return (size_t)1 << 18;
+}
+bool Mesh::KdBuiltOnDevice() const { return !ForceHostKd && m_Triangles.size() >= DeviceKdMinTriangles(); }
+void Mesh::BuildHostKd() {
+    ForceHostKd = true;
+    if (m_Invalidated || !m_KdTree.nodes.empty()) return;  // not compiled yet (Compile will build it) / already there
+    BuildKdTree();
+    static std::atomic<uint64_t> late{1ull << 61};
+    m_Revision = ++late;  // the flattened geometry changes: a renderer must not keep what it uploaded
+}
+void Mesh::BuildKdTree() {
+    m_KdTree = KdTreeFlat();
+    std::vector<uint32_t> all(m_Triangles.size());
+    for (size_t i = 0; i < all.size(); i++) all[i] = (uint32_t)i;
+    const MirrorTriView view{m_Triangles};
+    const rtbuild::Box3 root = {{m_BoundingBox.Min.X, m_BoundingBox.Min.Y, m_BoundingBox.Min.Z}, {m_BoundingBox.Max.X, m_BoundingBox.Max.Y, m_BoundingBox.Max.Z}};
+    rtbuild::KdBuilder<MirrorTriView> builder{view, m_KdTree};
+    builder.Build(all, root, 0, BuildForkDepth());
+}
+
 Triangle &Mesh::AddTriangle() {
     m_Triangles.emplace_back();
     return m_Triangles.back();
@@ -156,13 +181,11 @@ void Mesh::Compile() {
         gmx.X = std::max(gmx.X, mx.X); gmx.Y = std::max(gmx.Y, mx.Y); gmx.Z = std::max(gmx.Z, mx.Z);
     });
     auto T0 = std::chrono::steady_clock::now();
+    // The reference kd-tree of a big mesh is left to the device as well (RTHIP_UPLOAD_BUILD_KD: the same splits, level by level
+    // with all nodes of a level side by side; byte-identical arrays).  RE_KD_DEVICE_MIN_TRIS moves the limit (0 = always here).
     m_KdTree = KdTreeFlat();
-    std::vector<uint32_t> all(m_Triangles.size());
-    for (size_t i = 0; i < all.size(); i++) all[i] = (uint32_t)i;
+    if (!KdBuiltOnDevice()) BuildKdTree();
     const MirrorTriView view{m_Triangles};
-    const rtbuild::Box3 root = {{m_BoundingBox.Min.X, m_BoundingBox.Min.Y, m_BoundingBox.Min.Z}, {m_BoundingBox.Max.X, m_BoundingBox.Max.Y, m_BoundingBox.Max.Z}};
-    rtbuild::KdBuilder<MirrorTriView> builder{view, m_KdTree};
-    builder.Build(all, root, 0, BuildForkDepth());
     auto T1 = std::chrono::steady_clock::now();
     // The 4-wide BVH of a big mesh is left to the device (rthip_upload_scene_ex + RTHIP_UPLOAD_BUILD_BVH: milliseconds instead
     // of most of a second, and its leaf-order triangle copy is never made or uploaded); small meshes keep the host's

@@ -197,6 +197,7 @@ def test_threaded_scene_build_gives_the_single_threaded_arrays(host_lib, monkeyp
     reference's: sequential sums in triangle order per node)."""
     sd = scenes.config(4, cells=384)[0]   # 294 912 triangles: above the fork and the sliced-binning thresholds
     monkeypatch.setenv("RE_BVH_DEVICE_MIN_TRIS", "0")   # the host BVH builder is what is tested (at this size the device would build it)
+    monkeypatch.setenv("RE_KD_DEVICE_MIN_TRIS", "0")    # and the host kd builder
     out = {}
     for threads in ("1", "8", "3"):
         monkeypatch.setenv("RE_BUILD_THREADS", threads)

@@ -15,6 +15,7 @@ Fs = [int(f) for f in os.environ.get("RANKSHARE_F", "1,2,3").split(",")]
 Bs = [int(f) for f in os.environ.get("RANKSHARE_B", "1,2,4,8").split(",")]  # 0 = 8 per part (the bench's default)
 K = int(os.environ.get("RANKSHARE_K", "480"))
 ROT = os.environ.get("RANKSHARE_ROTATE", "0") == "1"
+REP = int(os.environ.get("RANKSHARE_REPEAT", "1"))
 for N in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]:
     prm = device.make_params(W, H, MR, part_index=0, part_count=N, layout=1)
     px = device.part_pixels(prm)
@@ -34,8 +35,12 @@ for N in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]:
             def sync():
                 for c in ctxs: c.synchronize()
             for k in range(4 * F): step(k)
-            sync(); t0 = time.perf_counter()
-            for k in range(K // B): step(k)
-            sync(); dt = (time.perf_counter() - t0) / (K // B * B) * 1e3
-            print(f"parts={N} batch={B} inflight={F}{' assemble every N-th call' if ROT else ''}: {dt:.4f} ms/frame  (0.595/N = {0.595 / N:.4f})", flush=True)
+            dts = []
+            for _ in range(REP):   # RANKSHARE_REPEAT bursts of K frames each (a 20-frame burst is ~1 ms: one sample says little)
+                sync(); t0 = time.perf_counter()
+                for k in range(K // B): step(k)
+                sync(); dts.append((time.perf_counter() - t0) / (K // B * B) * 1e3)
+            dts.sort(); dt = dts[len(dts) // 2]
+            print(f"parts={N} batch={B} inflight={F} burst={K}{' assemble every N-th call' if ROT else ''}: {dt:.4f} ms/frame median of {REP} "
+                  f"(min {dts[0]:.4f} max {dts[-1]:.4f})  (0.421/N = {0.421 / N:.4f})", flush=True)
             for c in ctxs: c.close()
