@@ -133,25 +133,29 @@ def cpu_baseline(sd, frames=3):
 def config4_line(local_rank, frames=5):
     """BASELINE configs[3] on ONE GPU, lone frames left in HBM: the 2 097 152-triangle height field + 16 reflective spheres,
     3840x2160, MaxRecursion 4 - the workload whose BVH + triangles (0.6 GB) do not fit L2, i.e. where HBM is the roof.
-    Measured twice: with the BVH the device builds at upload (RTHIP_UPLOAD_BUILD_BVH, top-down binned SAH in rthip_bvh.hip: the
-    library's default for meshes of 2^18 triangles and more, value / ms_per_frame) and with the one the host library builds (the
-    same algorithm on host threads: twice the start-up time, the same frames)."""
+    Measured twice: with the mesh's two trees - the 4-wide BVH the kernels walk and the reference's kd-tree - built on the device at
+    upload (RTHIP_UPLOAD_BUILD_BVH | RTHIP_UPLOAD_BUILD_KD: the library's default for meshes of 2^18 triangles and more; value /
+    ms_per_frame) and with both built by the host library on host threads (the same algorithms, the same frames)."""
     import torch
     from raytracing_amd import device, host, scenes
     sd, kw = scenes.config(4)
     w, h, mr = kw["width"], kw["height"], kw["max_recursion"]
     runs = {}
     saved = os.environ.get("RE_BVH_DEVICE_MIN_TRIS")
-    for name, env in (("bvh_built_on_device", "1"), ("bvh_built_on_host", "0")):
+    saved_kd = os.environ.get("RE_KD_DEVICE_MIN_TRIS")
+    for name, env in (("trees_built_on_device", "1"), ("trees_built_on_host", "0")):
         os.environ["RE_BVH_DEVICE_MIN_TRIS"] = env
+        os.environ["RE_KD_DEVICE_MIN_TRIS"] = env
+        tc = time.perf_counter()
+        hs = host.HostScene(sd, device_index=local_rank)   # the caller's part: 2 M triangles handed to Mesh::AddTriangle through the re:: API
         t0 = time.perf_counter()
-        hs = host.HostScene(sd, device_index=local_rank)
-        desc = hs.flatten()
+        desc = hs.flatten()                                # Scene::Compile (Raytracer.cpp:42) + flatten
         t1 = time.perf_counter()
         ctx = device.Context(local_rank)
-        ctx.upload(desc)
+        ctx.upload(desc)                                   # H2D + the trees the host left to the device
         ctx.synchronize()
         t2 = time.perf_counter()
+        up = ctx.upload_info()
         cam, prm = hs.camera(w, h), device.make_params(w, h, mr)
         fb = torch.zeros(w * h, dtype=torch.int32, device="cuda")
         for _ in range(3):
@@ -166,18 +170,22 @@ def config4_line(local_rank, frames=5):
         ts.sort()
         ms = ts[len(ts) // 2]
         runs[name] = {"rays_per_frame": int(rays), "ms_per_frame": ms, "value": rays / ms / 1e3, "frame_checksum": int(fb.to(torch.int64).sum().item()),
-                      "scene_compile_flatten_s": t1 - t0, "scene_upload_and_device_build_s": t2 - t1}
+                      "scene_construction_s": t0 - tc, "scene_compile_flatten_s": t1 - t0, "scene_upload_and_device_build_s": t2 - t1,
+                      "kd_tree": {"built_on": "device" if up.kd_meshes else "host", "device_ms": up.kd_device_ms, "nodes": int(up.kd_nodes) or None,
+                                  "leaf_refs": int(up.kd_refs) or None, "levels": int(up.kd_levels) or None},
+                      "bvh": {"built_on": "device" if up.bvh_meshes else "host", "nodes": int(up.bvh_nodes) or None}}
         ctx.close()
         del hs
-    if saved is None:
-        os.environ.pop("RE_BVH_DEVICE_MIN_TRIS", None)
-    else:
-        os.environ["RE_BVH_DEVICE_MIN_TRIS"] = saved
-    best = runs["bvh_built_on_device"]  # the default path for a mesh of this size
+    for key, val in (("RE_BVH_DEVICE_MIN_TRIS", saved), ("RE_KD_DEVICE_MIN_TRIS", saved_kd)):
+        if val is None:
+            os.environ.pop(key, None)
+        else:
+            os.environ[key] = val
+    best = runs["trees_built_on_device"]  # the default path for a mesh of this size
     out = {"workload": "BASELINE configs[3]: 2 097 152-triangle height field + 16 reflective spheres + SkyBox, 3840x2160, MaxRecursion 4, lone frames",
            "rays_per_frame": best["rays_per_frame"], "ms_per_frame": best["ms_per_frame"], "value": best["value"], "unit": "Mrays/s", "frames": frames,
-           "frame_checksum": best["frame_checksum"], "frames_identical": runs["bvh_built_on_host"]["frame_checksum"] == best["frame_checksum"],
-           "bvh_built_on_host": runs["bvh_built_on_host"], "bvh_built_on_device": runs["bvh_built_on_device"]}
+           "frame_checksum": best["frame_checksum"], "frames_identical": runs["trees_built_on_host"]["frame_checksum"] == best["frame_checksum"],
+           "trees_built_on_host": runs["trees_built_on_host"], "trees_built_on_device": runs["trees_built_on_device"]}
     pmc = _load(PMC_CFG4) or _load(os.path.join("profiles", "r01_pmc_summary_config4.json"))
     k = pmc and pmc["kernels"].get("k_trace_quad<false>")
     if k and k.get("hbm_bytes_per_frame"):

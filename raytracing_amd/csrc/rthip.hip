@@ -27,6 +27,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <future>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -1772,7 +1773,9 @@ static int upload_scene(rthip_ctx *c, const rthip_scene_desc *s, bool keep_geome
 
 // The kd-trees of the meshes that came without one, built on the device (rthip_kd.hip), appended behind the caller's trees in
 // the scene-wide kd arrays; their mesh-table entries are filled in.  Called with the caller's arrays not yet uploaded.
-static int upload_kd_arrays(rthip_ctx *c, const rthip_scene_desc *s, bool any_kd) {
+// `stream`: the context's own, or - any_kd - a stream of the caller's second thread (the build is one long dependent chain per
+// node that keeps a handful of waves busy: the BVH build and the triangle upload run beside it on the context's stream).
+static int upload_kd_arrays(rthip_ctx *c, const rthip_scene_desc *s, bool any_kd, hipStream_t stream) {
     int rc;
     if (!any_kd) {
         if ((rc = upload(c, c->kd_nodes, s->kd_nodes, sizeof(rthip_kdnode) * s->n_kd_nodes))) return rc;
@@ -1798,10 +1801,10 @@ static int upload_kd_arrays(rthip_ctx *c, const rthip_scene_desc *s, bool any_kd
         if (!c->mesh_device_kd[i]) continue;
         const rthip_mesh &m = c->mesh_table[i];
         if (verts.ensure(sizeof(double) * 9 * (size_t)m.tri_count)) { release(); return RTHIP_E_HIP; }
-        hipError_t e = hipMemcpyAsync(verts.p, s->tri_verts + (size_t)m.tri_base * 9, sizeof(double) * 9 * (size_t)m.tri_count, hipMemcpyHostToDevice, c->stream);
+        hipError_t e = hipMemcpyAsync(verts.p, s->tri_verts + (size_t)m.tri_base * 9, sizeof(double) * 9 * (size_t)m.tri_count, hipMemcpyHostToDevice, stream);
         if (e != hipSuccess) { release(); return fail(RTHIP_E_HIP, "rthip_upload_scene: %s", hipGetErrorString(e)); }
         char msg[256] = "";
-        rc = rthip_kd_build_device(c->stream, (const double *)verts.p, m.tri_count, s->mesh_bounds + (size_t)i * 6, &built[i].nodes, &built[i].bounds,
+        rc = rthip_kd_build_device(stream, (const double *)verts.p, m.tri_count, s->mesh_bounds + (size_t)i * 6, &built[i].nodes, &built[i].bounds,
                                    &built[i].refs, &built[i].planes, &built[i].info, msg, sizeof msg);
         if (rc) { release(); return fail(rc, "rthip_upload_scene: mesh %u: %s", i, msg); }
         const rthip_device_kd_info &k = built[i].info;
@@ -1818,7 +1821,7 @@ static int upload_kd_arrays(rthip_ctx *c, const rthip_scene_desc *s, bool any_kd
     if (c->kd_nodes.ensure(sizeof(rthip_kdnode) * n_nodes) || c->kd_bounds.ensure(sizeof(double) * 6 * n_nodes) || c->kd_refs.ensure(sizeof(uint32_t) * n_refs) ||
         c->kd_planes.ensure(sizeof(double) * n_planes)) { release(); return RTHIP_E_HIP; }
     hipError_t e = hipSuccess;
-    auto copy = [&](void *dst, const void *src, size_t bytes, hipMemcpyKind kind) { if (e == hipSuccess && bytes) e = hipMemcpyAsync(dst, src, bytes, kind, c->stream); };
+    auto copy = [&](void *dst, const void *src, size_t bytes, hipMemcpyKind kind) { if (e == hipSuccess && bytes) e = hipMemcpyAsync(dst, src, bytes, kind, stream); };
     copy(c->kd_nodes.p, s->kd_nodes, sizeof(rthip_kdnode) * s->n_kd_nodes, hipMemcpyHostToDevice);
     copy(c->kd_bounds.p, s->kd_bounds, sizeof(double) * 6 * s->n_kd_nodes, hipMemcpyHostToDevice);
     copy(c->kd_refs.p, s->kd_refs, sizeof(uint32_t) * s->n_kd_refs, hipMemcpyHostToDevice);
@@ -1840,7 +1843,7 @@ static int upload_kd_arrays(rthip_ctx *c, const rthip_scene_desc *s, bool any_kd
         for (int a = 0; a < 3; a++) { m.plane_base[a] = (uint32_t)at; m.plane_count[a] = k.plane_count[a]; at += k.plane_count[a]; }
         nb += k.n_nodes; rb += k.n_refs; pb += np;
     }
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
     release();
     if (e != hipSuccess) return fail(RTHIP_E_HIP, "rthip_upload_scene: %s", hipGetErrorString(e));
     return 0;
@@ -1876,7 +1879,24 @@ static int upload_scene_impl(rthip_ctx *c, const rthip_scene_desc *s, bool keep_
             else if (build_bvh && s->meshes[i].tri_count) any_device = c->mesh_device_bvh[i] = 1;
             else if (s->meshes[i].tri_count && s->n_bvh_nodes) mixed = true;
         }
-        if ((rc = upload_kd_arrays(c, s, any_kd))) return rc;
+        // the kd build runs on a second thread + stream while this one uploads the triangles and builds the BVHs; joined
+        // before the mesh table goes up (a std::async future also joins when an early return destroys it)
+        std::future<int> kd_job;
+        std::string kd_err;
+        hipStream_t kd_stream = nullptr;
+        struct StreamGuard { hipStream_t &s; ~StreamGuard() { if (s) (void)hipStreamDestroy(s); } } kd_stream_guard{kd_stream};
+        if (any_kd && hipStreamCreateWithFlags(&kd_stream, hipStreamNonBlocking) == hipSuccess) {
+            kd_job = std::async(std::launch::async, [&]() {
+                int r = hipSetDevice(c->device) == hipSuccess ? upload_kd_arrays(c, s, true, kd_stream) : RTHIP_E_HIP;
+                if (r) kd_err = rthip_last_error();
+                return r;
+            });
+        } else {
+            (void)hipGetLastError();
+            kd_stream = nullptr;
+            if ((rc = upload_kd_arrays(c, s, any_kd, c->stream))) return rc;
+        }
+        struct JoinGuard { std::future<int> &f; ~JoinGuard() { if (f.valid()) f.wait(); } } kd_join_guard{kd_job};  // (before the stream goes)
         if ((rc = upload(c, c->tris, s->tris, sizeof(rthip_tri) * s->n_tris))) return rc;
         if ((rc = upload(c, c->tri_normals, s->tri_normals, sizeof(double) * 9 * s->n_tris))) return rc;
         if (!any_device && !mixed) {
@@ -1936,6 +1956,7 @@ static int upload_scene_impl(rthip_ctx *c, const rthip_scene_desc *s, bool keep_
             release();
             if (e != hipSuccess) return fail(RTHIP_E_HIP, "rthip_upload_scene: %s", hipGetErrorString(e));
         }
+        if (kd_job.valid() && (rc = kd_job.get())) return fail(rc, "%s", kd_err.c_str());
         if ((rc = upload(c, c->meshes, c->mesh_table.data(), sizeof(rthip_mesh) * s->n_meshes))) return rc;
     }
     max_bvh_depth = 0;  // from the table the device holds (it carries the depths of the trees built here)

@@ -20,6 +20,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -47,7 +48,11 @@ struct KNode {
     uint32_t pool_off;        // leaves: first entry in the leaf pool
     uint32_t sub_nodes, sub_refs;  // subtree totals
     uint32_t pre, ref_base;        // pre-order index, first leaf reference of the subtree
-    uint32_t pad;
+    // the exact-sum shortcut (k_kd_grid_a / _b): smallest exponent of a set bit among the node's coordinates on its axis, the
+    // largest |coordinate| (as bits), and the integer sum of coordinate / 2^emin
+    int32_t emin;
+    unsigned long long amax_bits;
+    unsigned long long isum;
 };
 
 __global__ __launch_bounds__(kB) void k_kd_iota(uint32_t *list, uint32_t *owner, uint32_t n) {
@@ -55,13 +60,107 @@ __global__ __launch_bounds__(kB) void k_kd_iota(uint32_t *list, uint32_t *owner,
     if (i < n) { list[i] = i; owner[i] = 0u; }
 }
 
+// The exact-sum shortcut.  The reference's mean is a SEQUENTIAL fp64 sum, and a sequential sum only differs from the exact sum
+// through its roundings: if every coordinate of a node is a multiple of 2^e and 3n * max|coordinate| < 2^(53 + e), every partial
+// sum (a multiple of 2^e below 2^(53 + e)) is representable, no addition rounds, and the sequential sum IS the exact sum -
+// whatever the order.  Coordinates on a grid (a height field's x and z, anything modelled in 1/64ths or millimetres) qualify;
+// then the sum is an integer reduction over the whole level instead of one dependent chain per node.  Pass a: per node the
+// smallest set-bit exponent `emin` and the largest magnitude; pass b (nodes that qualify): the integer sum of coordinate / 2^emin.
+// Nodes that do not qualify (arbitrary doubles) take the chain in k_kd_median.
+const int32_t kEminNone = 0x7fffffff;
+__device__ __forceinline__ bool kd_exact_ok(uint32_t n, int32_t emin, unsigned long long amax_bits) {
+    if (emin == kEminNone) return true;                      // every coordinate is zero: the sum is +0.0
+    if ((amax_bits >> 52) >= 0x7ffull) return false;         // an infinity or a NaN takes the chain (and its IEEE rules)
+    const int32_t ea = (int32_t)(amax_bits >> 52) ? (int32_t)(amax_bits >> 52) - 1023 : -1022;  // |x| < 2^(ea + 1)
+    const int32_t bits_n = 64 - __clzll(3ull * (unsigned long long)n);                        // 3n < 2^bits_n
+    return bits_n + ea + 1 <= 53 + emin;
+}
+__device__ __forceinline__ int32_t kd_low_exponent(double x) {  // exponent of the lowest set bit of x (x finite, non-zero)
+    const unsigned long long b = (unsigned long long)__double_as_longlong(x);
+    const uint32_t e = (uint32_t)(b >> 52) & 0x7ffu;
+    const unsigned long long mant = (b & 0xfffffffffffffull) | (e ? (1ull << 52) : 0ull);
+    return (int32_t)(e ? e : 1u) - 1075 + (int32_t)(__ffsll((long long)mant) - 1);
+}
+// A wave takes kGridChunk consecutive entries of the level's list.  The entries of a node are contiguous and the owner ids grow
+// along the list, so the chunk lies inside ONE node iff its first and last entries have the same owner: then the lanes combine
+// and the wave sends one set of atomics (a level of 2 M entries in two nodes would otherwise send millions to two addresses).
+const uint32_t kGridChunk = 512;
+__global__ __launch_bounds__(kB) void k_kd_grid_a(uint32_t m, const uint32_t *list, const uint32_t *owner, KNode *nodes, const double *verts) {
+    const uint32_t lane = threadIdx.x & 63u, base = (blockIdx.x * (kB / 64) + (threadIdx.x >> 6)) * kGridChunk;
+    if (base >= m) return;
+    const uint32_t last = base + kGridChunk - 1u < m ? base + kGridChunk - 1u : m - 1u;
+    const bool uniform = owner[base] == owner[last];
+    int32_t emin = kEminNone;
+    unsigned long long amax = 0ull;
+    for (uint32_t e = base + lane; e <= last; e += 64u) {
+        const uint32_t id = owner[e];
+        const KNode &nd = nodes[id];
+        if (nd.n <= 1u || nd.depth == 100u) continue;
+        const double *v = verts + (size_t)list[e] * 9u + nd.depth % 3u;
+        int32_t le_min = kEminNone;
+        unsigned long long a_max = 0ull;
+        for (int k = 0; k < 3; k++) {
+            const double x = v[3 * k];
+            const unsigned long long a = (unsigned long long)__double_as_longlong(x) & 0x7fffffffffffffffull;
+            a_max = a > a_max ? a : a_max;
+            if (a != 0ull && (a >> 52) < 0x7ffull) { const int32_t le = kd_low_exponent(x); le_min = le < le_min ? le : le_min; }
+        }
+        if (uniform) {
+            emin = le_min < emin ? le_min : emin;
+            amax = a_max > amax ? a_max : amax;
+        } else {
+            if (le_min != kEminNone) atomicMin(&nodes[id].emin, le_min);
+            if (a_max) atomicMax(&nodes[id].amax_bits, a_max);
+        }
+    }
+    if (!uniform) return;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const int32_t oe = __shfl_xor(emin, off, 64);
+        const unsigned long long oa = (unsigned long long)__shfl_xor((long long)amax, off, 64);
+        emin = oe < emin ? oe : emin;
+        amax = oa > amax ? oa : amax;
+    }
+    if (lane == 0) {
+        const uint32_t id = owner[base];
+        if (emin != kEminNone) atomicMin(&nodes[id].emin, emin);
+        if (amax) atomicMax(&nodes[id].amax_bits, amax);
+    }
+}
+__global__ __launch_bounds__(kB) void k_kd_grid_b(uint32_t m, const uint32_t *list, const uint32_t *owner, KNode *nodes, const double *verts) {
+    const uint32_t lane = threadIdx.x & 63u, base = (blockIdx.x * (kB / 64) + (threadIdx.x >> 6)) * kGridChunk;
+    if (base >= m) return;
+    const uint32_t last = base + kGridChunk - 1u < m ? base + kGridChunk - 1u : m - 1u;
+    const bool uniform = owner[base] == owner[last];
+    long long total = 0;
+    for (uint32_t e = base + lane; e <= last; e += 64u) {
+        const uint32_t id = owner[e];
+        const KNode &nd = nodes[id];
+        if (nd.n <= 1u || nd.depth == 100u || nd.emin == kEminNone || !kd_exact_ok(nd.n, nd.emin, nd.amax_bits)) continue;
+        const double *v = verts + (size_t)list[e] * 9u + nd.depth % 3u;
+        long long part = 0;
+        for (int k = 0; k < 3; k++) part += (long long)ldexp(v[3 * k], -nd.emin);  // an integer below 2^53: exact
+        if (uniform) total += part;
+        else if (part) atomicAdd(&nodes[id].isum, (unsigned long long)part);
+    }
+    if (!uniform) return;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) total += __shfl_xor(total, off, 64);
+    if (lane == 0 && total) atomicAdd(&nodes[owner[base]].isum, (unsigned long long)total);
+}
+
 // Scene.cpp:25 (stop condition) and :36-47 (the mean): one wave per node of the level
-__global__ __launch_bounds__(64) void k_kd_median(KNode *nodes, uint32_t first, const double *verts, const uint32_t *list) {
-    __shared__ double buf[kChunk * 3];
+__global__ __launch_bounds__(64) void k_kd_median(KNode *nodes, uint32_t first, const double *verts, const uint32_t *list, int use_exact) {
+    __shared__ __attribute__((aligned(16))) double buf[kChunk * 3 + 48];
     KNode &nd = nodes[first + blockIdx.x];
     const uint32_t lane = threadIdx.x, n = nd.n, depth = nd.depth;
     if (n <= 1u || depth == 100u) {
         if (lane == 0) nd.flags |= F_LEAF;
+        return;
+    }
+    if (use_exact && kd_exact_ok(n, nd.emin, nd.amax_bits)) {  // no addition of the sequential sum rounds: it is the integer sum
+        const double sum = nd.emin == kEminNone ? 0.0 : ldexp((double)(long long)nd.isum, nd.emin);
+        if (lane == 0) nd.split = sum / (double)(3ull * (unsigned long long)n);
         return;
     }
     const uint32_t axis = depth % 3u;
@@ -91,13 +190,35 @@ __global__ __launch_bounds__(64) void k_kd_median(KNode *nodes, uint32_t first, 
         __syncthreads();
         if (c0 + kChunk < n) fetch(c0 + kChunk);
         const uint32_t cnt3 = (n - c0 < kChunk ? n - c0 : kChunk) * 3u;
-        // the chain: every lane runs it on the same (broadcast) LDS words; vertices 0, 1, 2 of a triangle, triangles in list order
+        // The chain: every lane runs it on the same (broadcast) LDS words; vertices 0, 1, 2 of a triangle, triangles in list
+        // order.  Blocks of 16 words, the next block read from LDS while the current one is added (the buffer is padded: the
+        // read ahead of the last block stays inside it), so that the chain waits for its own additions only.
+        constexpr uint32_t kW = 16;
+        double a[kW], b[kW];  // two register blocks used in turn (copying one to the other cost as much as the additions)
+#pragma unroll
+        for (uint32_t k = 0; k < kW; k++) a[k] = buf[k];
         uint32_t j = 0;
-        for (; j + 8u <= cnt3; j += 8u) {
-            const double a0 = buf[j], a1 = buf[j + 1], a2 = buf[j + 2], a3 = buf[j + 3], a4 = buf[j + 4], a5 = buf[j + 5], a6 = buf[j + 6], a7 = buf[j + 7];
-            sum += a0; sum += a1; sum += a2; sum += a3; sum += a4; sum += a5; sum += a6; sum += a7;
+        for (; j + 2u * kW <= cnt3; j += 2u * kW) {
+#pragma unroll
+            for (uint32_t k = 0; k < kW; k++) b[k] = buf[j + kW + k];
+#pragma unroll
+            for (uint32_t k = 0; k < kW; k++) sum += a[k];
+#pragma unroll
+            for (uint32_t k = 0; k < kW; k++) a[k] = buf[j + 2u * kW + k];
+#pragma unroll
+            for (uint32_t k = 0; k < kW; k++) sum += b[k];
         }
-        for (; j < cnt3; j++) sum += buf[j];
+        // at most 2 kW - 1 words left: a[] holds buf[j .. j + kW)
+#pragma unroll
+        for (uint32_t k = 0; k < kW; k++)
+            if (j + k < cnt3) sum += a[k];
+        if (j + kW < cnt3) {
+#pragma unroll
+            for (uint32_t k = 0; k < kW; k++) b[k] = buf[j + kW + k];
+#pragma unroll
+            for (uint32_t k = 0; k < kW; k++)
+                if (j + kW + k < cnt3) sum += b[k];
+        }
         __syncthreads();
     }
     const double median = sum / (double)(3ull * (unsigned long long)n);  // `median /= 3 * n` (size_t -> double)
@@ -175,6 +296,7 @@ __global__ __launch_bounds__(kB) void k_kd_children(KNode *nodes, uint32_t first
             ch.left = ch.right = kNone;
             ch.flags = side ? F_RIGHT : 0u;
             ch.depth = nd.depth + 1u;
+            ch.emin = kEminNone;
             nodes[child] = ch;
             (side ? nd.right : nd.left) = child;
             child++;
@@ -336,11 +458,14 @@ static int build(hipStream_t stream, const double *d_verts, uint32_t n, const do
         for (int a = 0; a < 3; a++) { root.lo[a] = root_bounds[a]; root.hi[a] = root_bounds[3 + a]; }
         root.n = n;
         root.parent = root.left = root.right = kNone;
+        root.emin = kEminNone;
         KHIP(hipMemcpyAsync(nodes.p, &root, sizeof root, hipMemcpyHostToDevice, stream));
         KHIP(hipStreamSynchronize(stream));  // (`root` is a local)
     }
     if (n) hipLaunchKernelGGL(k_kd_iota, grid(n), dim3(kB), 0, stream, list_a.as<uint32_t>(), owner_a.as<uint32_t>(), n);
     Buf *cur = &list_a, *nxt = &list_b, *own = &owner_a, *own_nxt = &owner_b;
+    int use_exact = 1;  // RTHIP_KD_EXACT_SUMS=0: every node takes the sequential chain (tests: both routes give the same tree)
+    if (const char *e = getenv("RTHIP_KD_EXACT_SUMS")) use_exact = atoi(e) != 0;
     std::vector<uint32_t> level_first = {0u};
     uint32_t total_nodes = 1, first = 0, nn = 1, m = n, pool_total = 0;
     auto scan_u64 = [&](const unsigned long long *in, unsigned long long *out, size_t count) -> hipError_t {
@@ -362,7 +487,12 @@ static int build(hipStream_t stream, const double *d_verts, uint32_t n, const do
             snprintf(err, err_len, "kd build: more than 101 levels");
             return RTHIP_E_HIP;
         }
-        hipLaunchKernelGGL(k_kd_median, dim3(nn), dim3(64), 0, stream, nodes.as<KNode>(), first, d_verts, cur->as<uint32_t>());
+        if (use_exact && m) {
+            const dim3 gchunks((uint32_t)(((size_t)m + kGridChunk * (kB / 64) - 1) / (kGridChunk * (kB / 64))));
+            hipLaunchKernelGGL(k_kd_grid_a, gchunks, dim3(kB), 0, stream, m, cur->as<uint32_t>(), own->as<uint32_t>(), nodes.as<KNode>(), d_verts);
+            hipLaunchKernelGGL(k_kd_grid_b, gchunks, dim3(kB), 0, stream, m, cur->as<uint32_t>(), own->as<uint32_t>(), nodes.as<KNode>(), d_verts);
+        }
+        hipLaunchKernelGGL(k_kd_median, dim3(nn), dim3(64), 0, stream, nodes.as<KNode>(), first, d_verts, cur->as<uint32_t>(), use_exact);
         if (m) {
             KHIP(key.reserve(sizeof(unsigned long long) * (size_t)m, 0, stream));
             KHIP(S.reserve(sizeof(unsigned long long) * (size_t)m, 0, stream));

@@ -208,6 +208,7 @@ public:
     explicit Mesh(SceneNode *owner) : Shape(owner) {}
     NormalModes NormalMode = NormalModes::Face;
     Triangle &AddTriangle();
+    void ReserveTriangles(size_t n) { m_Triangles.reserve(n); }  // additive: a caller that knows the count avoids the vector's regrowth copies
     void Compile() override;  // Scene.cpp:386-414
     void Invalidate() { m_Invalidated = true; }
     const std::vector<Triangle> &GetTriangles() const { return m_Triangles; }  // additive

@@ -218,6 +218,7 @@ int sb_plane(sb_scene *s, int node, int mat, const double n[3]) {
 int sb_mesh(sb_scene *s, int node, int mat, int normal_mode, int ntris, const double *verts, const double *normals) {
     if (!node_ok(s, node, mat) || ntris < 0 || (ntris && !verts)) return -1;
     auto mesh = s->nodes[node]->AddComponent<Mesh>();
+    mesh->ReserveTriangles((size_t)ntris);
     for (int i = 0; i < ntris; i++) {
         Triangle &t = mesh->AddTriangle();
         t.Vertices = {V3(verts + i * 9), V3(verts + i * 9 + 3), V3(verts + i * 9 + 6)};

@@ -55,9 +55,12 @@ def test_device_kd_tree_of_the_bunny_is_the_reference_tree(monkeypatch, golden):
     assert info.kd_nodes == 6881 and info.kd_refs == 26456 and info.kd_levels == 17
 
 
+@pytest.mark.parametrize("exact", ["1", "0"])
 @pytest.mark.parametrize("cells", [24, 96, 384])
-def test_device_kd_tree_of_height_fields(monkeypatch, cells):
-    """the config-4 mesh generator at 1 152, 18 432 and 294 912 triangles (x / z on a grid: exact sums; y: arbitrary doubles)"""
+def test_device_kd_tree_of_height_fields(monkeypatch, cells, exact):
+    """the config-4 mesh generator at 1 152, 18 432 and 294 912 triangles: x / z lie on a grid, so their sequential sums are exact
+    and the builder takes them as integer reductions (RTHIP_KD_EXACT_SUMS=0: the dependent chain for every node, as for y)"""
+    monkeypatch.setenv("RTHIP_KD_EXACT_SUMS", exact)
     sd = _mesh_scene(scenes.heightfield_mesh(cells, seed=1234)[0], f"height field {cells}")
     dev, info = _kd_of(monkeypatch, sd, True)
     ref, _ = _kd_of(monkeypatch, sd, False)
@@ -81,6 +84,24 @@ def test_device_kd_tree_of_random_meshes(monkeypatch, seed):
     dev, _ = _kd_of(monkeypatch, sd, True)
     ref, _ = _kd_of(monkeypatch, sd, False)
     _assert_same_tree(dev, ref, f"random mesh {seed} ({n} triangles)")
+
+
+@pytest.mark.parametrize("bits", [12, 30, 37, 38, 39, 40, 41, 46, 52])
+def test_device_kd_tree_on_grid_coordinates_around_the_exactness_limit(monkeypatch, bits):
+    """coordinates that are integers of `bits` bits times 2^-7: the sequential sum of 3n of them is exact as long as it stays
+    below 2^53 units - the builder's integer route - and rounds beyond (the chain).  Around the limit (3n = 9 000 is 14 bits:
+    39 + 14 = 53) both routes must give the host builder's tree; zeros, negative zeros and a subnormal are mixed in."""
+    rng = np.random.default_rng(bits)
+    n = 3000
+    k = rng.integers(-(1 << bits), 1 << bits, (n, 9), dtype=np.int64)
+    k[:, 3:] = k[:, :3].repeat(2).reshape(n, 6)[:, [0, 2, 4, 1, 3, 5]] + rng.integers(-(1 << max(bits - 6, 1)), 1 << max(bits - 6, 1), (n, 6))  # small triangles
+    v = k.astype(np.float64) * 2.0 ** -7
+    v[7, 0] = 0.0; v[8, 1] = -0.0; v[9, 2] = 5e-324
+    sd = _mesh_scene(v, f"grid coordinates, {bits} bits")
+    dev, _ = _kd_of(monkeypatch, sd, True)
+    ref, _ = _kd_of(monkeypatch, sd, False)
+    _assert_same_tree(dev, ref, f"{bits}-bit grid")
+    assert dev[0].node_count > 50
 
 
 @pytest.mark.parametrize("kind", ["one", "two", "points_chain", "identical", "empty_side"])
