@@ -22,7 +22,8 @@ Prints ONE JSON line (rank 0).  Extra objects: "roofline" (dominant kernel k_tra
 SURVEY.md §8d's per-unit weights x counts measured on this call, against the fp64 vector peak; the HBM fraction next to it
 from the PMC-measured traffic), "config4" (BASELINE configs[3], the 2 M-triangle 4K frame: the config whose roof IS HBM),
 "single_frame_latency_ms" / "ms_per_frame_with_d2h" in "config", and "cpu_baseline" (the genuine reference compiled in
-oracle/_ref - or the C oracle port - timed on the host cores, NumThreads 16 and 8, medians of 3 frames).
+oracle/_ref - or the C oracle port - timed on the host cores, NumThreads 16 and 8, medians of 5 frames), and "config2" / "config3_closeup" /
+"config5": the other BASELINE configs as lone frames on one GPU, each with its own roofline object.
 
 `python bench.py --gpus N` with N > 1 and no launcher around it starts its own N ranks (torch.distributed.run as a child
 process) and relays rank 0's line and the exit code.
@@ -49,6 +50,7 @@ FP64_VALU_PEAK_UNFUSED_TFLOPS = 39.3
 PMC_CFG3 = os.path.join("profiles", "r02_pmc_summary_config3_batch8.json")
 PMC_CFG4 = os.path.join("profiles", "r02_pmc_summary_config4.json")
 PMC_TRAFFIC = os.path.join("profiles", "r02_pmc_traffic.json")
+PMC_CFG5_HBM = os.path.join("profiles", "r03_pmc_config5_hbm.json")
 
 
 # ALGORITHMIC flops of the dominant kernel (SURVEY.md §8d "ALGORITHMIC flops per ray": fixed weights x measured counts), for
@@ -59,11 +61,145 @@ PMC_TRAFFIC = os.path.join("profiles", "r02_pmc_traffic.json")
 #                      (10 + 3 sub), the hit point (1 div + 6), v2 (3), two more dots (10), v / w / u (10), |O-P|^2 (8), compares
 #   180 per shape-table entry tested: SURVEY's weight (two 4x4 mat-vec, normalise, intersect, world point, d^2)
 #   140 per ray      : hit record of the winner (hit_details: transforms, barycentric normal blend, two normalisations)
-FLOPS_NODE, FLOPS_TRI, FLOPS_SHAPE, FLOPS_RAY = 72, 54, 180, 140
+#   25 per shape-table entry that the bounding-ball test rejects (ball_missed: two 3-dots, a difference, the compares) - such
+#                      an entry never reaches the transform and the intersection the 180 stand for
+FLOPS_NODE, FLOPS_TRI, FLOPS_SHAPE, FLOPS_RAY, FLOPS_BALL = 72, 54, 180, 140, 25
+
+
+def shape_flops(entries, entries_full):
+    return FLOPS_SHAPE * int(entries_full) + FLOPS_BALL * (int(entries) - int(entries_full))
 
 
 def algorithmic_flops(st):
-    return FLOPS_NODE * st.kd_nodes_visited + FLOPS_TRI * st.kd_tris_tested + FLOPS_SHAPE * st.shape_tests + FLOPS_RAY * st.rays_hard
+    return FLOPS_NODE * st.kd_nodes_visited + FLOPS_TRI * st.kd_tris_tested + shape_flops(st.shape_tests, st.shape_tests_full) + FLOPS_RAY * st.rays_hard
+
+
+# ... and of the two kernels that shade (SURVEY.md §8d's weights): k_trace_easy generates the level-0 rays (30 each), tests every
+# ray of a level against the shape table (180 per entry), shades the rays it finishes itself - material (per InterpolatedMaterial
+# node: the noise + 24 for the wrap and the lerps; Perlin 500, Worley 300, Marble 525, checker 8), SkyBox on a miss (Perlin 500 + 30
+# for the mix and the sun disc), 30 per light term, 12 per reflected ray; k_shade does the shading part for the rays that needed a
+# mesh walk.  Counts come from a counting context (rthip_stats.shape_hits / background_evals / rays_*_by_kernel).
+FLOPS_RAYGEN, FLOPS_LIGHT, FLOPS_REFLECT, FLOPS_SKY, FLOPS_LERP = 30, 30, 12, 530, 24
+FLOPS_NOISE = {0: 8, 1: 500, 2: 300, 3: 525}  # RTHIP_NOISE_CHECKER / PERLIN / WORLEY / MARBLE
+
+
+def material_flops(desc_ptr):
+    """(flops of one material evaluation per shape ordinal, flops of one background evaluation) of a flattened scene"""
+    from raytracing_amd import device
+    shapes, mats, noises, bg = device.scene_tables(desc_ptr)
+    per_shape = []
+    for sh in shapes:
+        root = sh.material
+        per_shape.append(sum(FLOPS_NOISE[noises[mats[k].noise].type] + FLOPS_LERP for k in range(mats[root].first_op, root + 1) if mats[k].op == 1))
+    return per_shape, (FLOPS_SKY if bg == 2 else 0)
+
+
+def kernel_flops(st, mat, sky):
+    """algorithmic flops of one call, by kernel, from the statistics of a counting context"""
+    shaded = lambda k: sum(int(st.shape_hits[k][i]) * mat[min(i, len(mat) - 1)] for i in range(64) if st.shape_hits[k][i]) if mat else 0
+    shading = lambda k: shaded(k) + sky * int(st.background_evals[k]) + FLOPS_LIGHT * int(st.rays_shadow_by_kernel[k]) + FLOPS_REFLECT * int(st.rays_reflect_by_kernel[k])
+    return {"k_trace_quad": int(algorithmic_flops(st)),
+            "k_trace_easy": int(FLOPS_RAYGEN * st.rays_primary + shape_flops(st.shape_tests_easy, st.shape_tests_easy_full) + shading(0)),
+            "k_shade": int(shading(1))}
+
+
+def kernel_ms(st):
+    """summed duration of each kernel over the levels of one call (a context created with RTHIP_PROFILE_LAUNCHES=1: HIP events around
+    plain launches that have the GPU to themselves)"""
+    n = max(1, st.launches_trace)
+    return {"k_trace_quad": float(st.ms_trace), "k_trace_easy": float(st.ms_easy), "k_shade": float(sum(st.level_ms_shade[i] for i in range(min(n, 17))))}
+
+
+def measured_pmc(kernel, rel):
+    j = _load(rel)
+    k = j and j["kernels"].get(kernel)
+    if not k:
+        return None
+    out = {key: k[key] for key in ("valu_issue_util", "wave_time_waiting", "l2_hit_rate", "active_lanes_per_valu_inst", "valu_insts_per_frame") if key in k}
+    if "valu_issue_util" in out and "active_lanes_per_valu_inst" in out:
+        out["valu_lane_cycle_util"] = out["valu_issue_util"] * out["active_lanes_per_valu_inst"] / 64.0
+    out["source"] = rel
+    return out
+
+
+def config_object(workload, sd, kw, local_rank, frames=5, hbm_pmc=None):
+    """One more BASELINE config on ONE GPU, lone frames left in HBM (every config's GPU numbers in the driver line):
+    median ms / frame and Mrays/s of `frames` frames replayed from the captured launch graph, the checksum of the frame, the
+    start-up times, and the frame's position against the fp64 vector roof: algorithmic flops of the three ray kernels (a counting
+    context) over the frame time, with each kernel's own share (per-launch HIP events of a profiling context)."""
+    import torch
+    from raytracing_amd import device, host
+    w, h, mr = kw["width"], kw["height"], kw["max_recursion"]
+    tc = time.perf_counter()
+    hs = host.HostScene(sd, device_index=local_rank)
+    t0 = time.perf_counter()
+    desc = hs.flatten()
+    t1 = time.perf_counter()
+    cam, prm = hs.camera(w, h), device.make_params(w, h, mr)
+    fb = torch.zeros(w * h, dtype=torch.int32, device="cuda")
+    mat, sky = material_flops(desc)
+
+    def context(env=None):
+        if env:
+            os.environ[env] = "1"
+        c = device.Context(local_rank)
+        if env:
+            os.environ[env] = "0"
+        c.upload(desc)
+        return c
+
+    ctx = context()
+    ctx.synchronize()
+    t2 = time.perf_counter()
+    up = ctx.upload_info()
+    for _ in range(3):
+        ctx.render_device(cam, prm, fb.data_ptr(), sync=True)
+    st = ctx.stats()
+    rays = int(st.rays_primary + st.rays_shadow + st.rays_reflect)
+    ts, wall = [], []
+    for _ in range(frames):
+        t = time.perf_counter()
+        ctx.render_device(cam, prm, fb.data_ptr(), sync=True)
+        wall.append((time.perf_counter() - t) * 1e3)   # the synchronous call: + the statistics read-back
+        ts.append(float(ctx.stats().ms_total))          # the frame on the device: HIP events around its launches
+    ts.sort()
+    wall.sort()
+    ms = ts[len(ts) // 2]
+    checksum = int(fb.to(torch.int64).sum().item())
+    ctx.close()
+    c = context("RTHIP_COUNTERS")
+    c.render_device(cam, prm, fb.data_ptr(), sync=True)
+    cst = c.stats()
+    c.close()
+    c = context("RTHIP_PROFILE_LAUNCHES")
+    for _ in range(2):
+        c.render_device(cam, prm, fb.data_ptr(), sync=True)
+    pst = c.stats()
+    c.close()
+    fl, kms = kernel_flops(cst, mat, sky), kernel_ms(pst)
+    total = sum(fl.values())
+    tf = total / (ms * 1e-3) / 1e12
+    out = {"workload": workload, "rays_per_frame": rays, "ms_per_frame": ms, "ms_per_frame_samples": ts, "ms_per_synchronous_call": wall[len(wall) // 2],
+           "value": rays / ms / 1e3, "unit": "Mrays/s",
+           "frames": frames, "frame_checksum": checksum,
+           "scene_construction_s": t0 - tc, "scene_compile_flatten_s": t1 - t0, "scene_upload_and_device_build_s": t2 - t1,
+           "trees": {"kd_built_on": "device" if up.kd_meshes else "host", "kd_device_ms": up.kd_device_ms, "bvh_built_on": "device" if up.bvh_meshes else "host"},
+           "roofline": {"bound": "valu_fp64", "achieved": tf, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_VALU_PEAK_TFLOPS,
+                        "frac_of_unfused_peak": tf / FP64_VALU_PEAK_UNFUSED_TFLOPS, "algorithmic_flops_per_frame": total, "traffic": None,
+                        "note": "whole frame: algorithmic flops of k_trace_easy + k_trace_quad + k_shade over the frame's wall time",
+                        "kernels": [{"kernel": k, "algorithmic_flops_per_frame": fl[k], "ms_per_frame": kms[k],
+                                     "achieved": (fl[k] / (kms[k] * 1e-3) / 1e12) if kms[k] > 0 else None,
+                                     "frac": (fl[k] / (kms[k] * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS) if kms[k] > 0 else None} for k in fl],
+                        "counts": {"bvh_steps": int(cst.kd_nodes_visited), "triangle_tests": int(cst.kd_tris_tested), "shape_entries_walk": int(cst.shape_tests),
+                                   "shape_entries_walk_past_ball_test": int(cst.shape_tests_full), "shape_entries_easy": int(cst.shape_tests_easy),
+                                   "shape_entries_easy_past_ball_test": int(cst.shape_tests_easy_full), "rays_walked": int(cst.rays_hard),
+                                   "background_evals": [int(cst.background_evals[0]), int(cst.background_evals[1])]}}}
+    if hbm_pmc:
+        out["roofline"]["hbm"] = hbm_pmc
+    del hs
+    return out
+
+
 
 
 def _load(rel):
@@ -96,9 +232,9 @@ def measured_valu(rel=PMC_CFG3, fallback=os.path.join("profiles", "r01_pmc_summa
     return out
 
 
-def cpu_baseline(sd, frames=3):
+def cpu_baseline(sd, frames=5):
     """Times the CPU renderer on the host cores on a bounded sample of the same workload: `frames` whole 1080p frames at
-    NumThreads = min(16, host cores) and at NumThreads = 8 (the Sandbox's setting, Sandbox/Sandbox.cpp:139), medians."""
+    NumThreads = min(16, host cores) and at NumThreads = 8 (the Sandbox's setting, Sandbox/Sandbox.cpp:139), medians of 5."""
     import oracle
     cores = min(16, os.cpu_count() or 1)
     if oracle.have_ref():
@@ -237,6 +373,8 @@ def main():
                     "--no-extras`: every k_trace_quad launch of the process then has the timed region's size, so the profiler's average "
                     "duration of that kernel is comparable with roofline.avg_launch_ms")
     ap.add_argument("--no-config4", action="store_true", help="skip the config-4 object (2 M-triangle scene: ~3 s of host build + 0.6 GB upload)")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the config2 / config3_closeup / config5 objects")
+    ap.add_argument("--no-config5", action="store_true", help="skip the config-5 object (10.5 M triangles at 8K on one GPU: ~40 s of scene construction)")
     ap.add_argument("--collective", choices=["gather", "all_gather"], default="gather", help="framebuffer exchange: gather to rank 0 "
                     "(each peer sends its part once) or all-gather (every rank ends up with the frames)")
     ap.add_argument("--gather-dst", choices=["rotate", "0"], default="rotate", help="with --collective gather: the rank that receives and "
@@ -419,6 +557,7 @@ def main():
         pctxs[0].render_batch_device(cam_run(0, B), prm, mines[0].data_ptr(), sync=True)
     st = pctxs[0].stats()
     launch_ms = st.ms_trace / max(1, st.launches_trace)
+    kfl, kms = kernel_flops(cst, *material_flops(desc)), kernel_ms(st)
     over = []
 
     def overlapped(j):
@@ -462,8 +601,20 @@ def main():
             ctxs[0].host_free(pinned)
     for c in ctxs[1:]:
         c.close()
+    others = {}
     if world == 1 and rank == 0 and not args.no_extras and not args.no_config4:
         cfg4 = config4_line(local_rank)
+    if world == 1 and rank == 0 and not args.no_extras and not args.no_other_configs:
+        # the other BASELINE configs' GPU numbers: Demo 1 (noise materials, no mesh), the close-up of the bunny the
+        # survey asks for (camera (0,0,2.2): the mesh fills the view, the walk dominates), and config 5 on ONE GPU
+        others["config2"] = config_object("BASELINE configs[1]: Demo 1 spheres (Marble / Worley / Perlin materials) + checker plane + SkyBox, 1920x1080, "
+                                          "MaxRecursion 3, lone frames", *scenes.config(2), local_rank)
+        others["config3_closeup"] = config_object("BASELINE configs[2] from camera (0,0,2.2) (SURVEY.md §8d: the bunny fills the view, kd / BVH traversal "
+                                                  "dominates), 1920x1080, MaxRecursion 3, lone frames", *scenes.config(3, cam_z=2.2), local_rank)
+        if not args.no_config5:
+            others["config5"] = config_object("BASELINE configs[4] on ONE GPU: five rotated / scaled 2 097 152-triangle height fields (10 485 760 triangles) + 16 "
+                                              "reflective spheres + checker plane + SkyBox, 7680x4320, MaxRecursion 8, lone frames (two workspace chunks)",
+                                              *scenes.config(5), local_rank, frames=3, hbm_pmc=_load(PMC_CFG5_HBM))
     red_dev = "cpu" if args.rehearse_on_one_gpu else "cuda"
     rays_t = torch.tensor([float(my_rays_timed), float(path_rays[0])], dtype=torch.float64, device=red_dev)
     dt_t = torch.tensor(samples, dtype=torch.float64, device=red_dev)
@@ -511,11 +662,21 @@ def main():
                          "kernel": "k_trace_quad", "launches_per_call": int(st.launches_trace), "avg_launch_ms": launch_ms,
                          "avg_launch_ms_calls_in_flight": launch_ms_overlapped,
                          "algorithmic_flops_per_call_rank0": int(aflops),
-                         "flop_weights": {"bvh_step_4_boxes_fp32": FLOPS_NODE, "triangle_test_fp64": FLOPS_TRI, "shape_entry_fp64": FLOPS_SHAPE, "hit_record_fp64": FLOPS_RAY},
+                         "flop_weights": {"bvh_step_4_boxes_fp32": FLOPS_NODE, "triangle_test_fp64": FLOPS_TRI, "shape_entry_fp64": FLOPS_SHAPE,
+                                          "shape_entry_rejected_by_ball_test": FLOPS_BALL, "hit_record_fp64": FLOPS_RAY},
                          "counts_per_call_rank0": {"bvh_steps": int(cst.kd_nodes_visited), "triangle_tests": int(cst.kd_tris_tested),
-                                                   "shape_entries": int(cst.shape_tests), "rays": int(cst.rays_hard)},
+                                                   "shape_entries": int(cst.shape_tests_full), "shape_entries_rejected_by_ball_test": int(cst.shape_tests - cst.shape_tests_full),
+                                                   "rays": int(cst.rays_hard)},
                          "frames_per_call": B,
                          "pmc": measured_valu(),
+                         # every ray kernel of the timed regime, not only the dominant one: algorithmic flops of one call (the counting
+                         # context above) over the kernel's summed launch durations in that call (plain launches alone on the GPU)
+                         "kernels": [{"kernel": k, "algorithmic_flops_per_call": kfl[k], "ms_per_call": kms[k], "launches_per_call": int(st.launches_trace),
+                                      "achieved": kfl[k] / (kms[k] * 1e-3) / 1e12 if kms[k] > 0 else None,
+                                      "frac": kfl[k] / (kms[k] * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS if kms[k] > 0 else None,
+                                      "frac_of_unfused_peak": kfl[k] / (kms[k] * 1e-3) / 1e12 / FP64_VALU_PEAK_UNFUSED_TFLOPS if kms[k] > 0 else None,
+                                      "share_of_call": kms[k] / sum(kms.values()),
+                                      "pmc": measured_pmc(k + ("<true>" if k == "k_shade" else "<false>"), PMC_CFG3)} for k in kfl],
                          "note": "peak = 78.6 TFLOP/s fp64 vector with FMA; the kernels are built with -ffp-contract=off (bit parity with the "
                                  "non-fused reference), so an instruction is one flop and the usable peak is 39.3 (frac_of_unfused_peak).  "
                                  "`pmc` is the measured side: share of SIMD cycles issuing VALU x active lanes per instruction.  "
@@ -524,6 +685,7 @@ def main():
         }
         if cfg4 is not None:
             out["config4"] = cfg4
+        out.update(others)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sd)
         print(json.dumps(out), flush=True)

@@ -268,6 +268,16 @@ typedef struct {
     /* since the context was created: launch graphs captured (one per frame SHAPE: params, frames per call, output and workspace
      * pointers, scene - the cameras are not part of it) and calls served by replaying one */
     uint32_t graphs_captured, graph_replays;
+    /* RTHIP_COUNTERS=1: what the two shading kernels shaded in the last call, [0] = k_trace_easy (the rays it finishes itself),
+     * [1] = k_shade (the rays that needed a mesh walk): hits per shape ordinal (shapes >= 63 share the last entry) and
+     * Background::GetColor evaluations; the units of the flop accounting of those kernels (bench.py) */
+    uint64_t shape_hits[2][64];
+    uint64_t background_evals[2];
+    /* rays_shadow / rays_reflect split by the kernel that shaded the parent ray (same [0] / [1]; always collected) */
+    uint64_t rays_shadow_by_kernel[2], rays_reflect_by_kernel[2];
+    /* RTHIP_COUNTERS=1: of shape_tests / shape_tests_easy, the entries that passed the bounding-ball test and went through the
+     * world -> local transform and the intersection (meshes: the BVH root boxes / the walk); the others cost the ball test only */
+    uint64_t shape_tests_full, shape_tests_easy_full;
 } rthip_stats;
 
 /* ---- lifecycle ---- */

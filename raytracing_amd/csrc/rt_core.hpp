@@ -132,6 +132,7 @@ struct KdCounters {
     uint32_t nodes, leaves, tris, pops, shapes, mesh_hits;
     uint32_t wave_steps, wave_tris;  // loop iterations the WAVE executed (one lane counts each): divergence diagnostic
     uint32_t fetch_cycles;           // cycles the wave waited for BVH node fetches (one lane counts)
+    uint32_t shapes_full;            // shape-table entries that passed the bounding-ball test (world -> local transform + intersection / root boxes)
 };
 #if defined(__HIP_DEVICE_COMPILE__)
 __device__ __forceinline__ uint32_t rt_first_active() {
@@ -1091,6 +1092,7 @@ RT_HD int32_t cast_ray_id(const SceneView &sv, V3 o, V3 d, KdStack &st, bool any
         }
         const int32_t type = sh->type;
         if (type != RTHIP_SHAPE_PLANE && ball_missed(sh->bound_c[0], sh->bound_c[1], sh->bound_c[2], sh->bound_r2, o, d)) continue;
+        if (COUNT) cnt->shapes_full++;
         V3 lo = xform(inv, o, 1.0);
         V3 ld = normalized(xform(inv, d, 0.0));
         V3 p;

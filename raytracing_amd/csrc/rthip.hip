@@ -107,7 +107,9 @@ static const uint32_t kMaxGridQuad = 8192;     // quad kernel (64 rays per workg
 static const size_t kMaxLevelRays = (size_t)1 << 24;  // level-0 rays per chunk (bounds the workspace); RTHIP_CHUNK_RAYS overrides (tests)
 static const uint32_t kMaxGridLevel = 4096;   // k_trace_easy / k_shade / k_trace: grid-stride over a bounded grid (one workgroup per 256 rays
                                               // costs 6 % when calls overlap: LDS table staging, statistics flush and launch per workgroup)
-enum { ST_KD_NODES = 0, ST_KD_TRIS, ST_KD_LEAVES, ST_KD_POPS, ST_SHAPES, ST_MESH_HITS, ST_KD_MAXRAY, ST_WAVE_STEPS_MAX, ST_WAVE_TRIS_MAX, ST_WAVE_STEPS, ST_WAVE_TRIS, ST_WAVE_CYCLES_MAX, ST_FETCH_CYCLES, ST_SHAPES_EASY, ST_COUNT };
+static const uint32_t kShadeCountShapes = 64;                      // per-shape hit counters of a counting context (shapes beyond share the last)
+static const uint32_t kShadeCounts = kShadeCountShapes + 1;        // + background evaluations
+enum { ST_KD_NODES = 0, ST_KD_TRIS, ST_KD_LEAVES, ST_KD_POPS, ST_SHAPES, ST_MESH_HITS, ST_KD_MAXRAY, ST_WAVE_STEPS_MAX, ST_WAVE_TRIS_MAX, ST_WAVE_STEPS, ST_WAVE_TRIS, ST_WAVE_CYCLES_MAX, ST_FETCH_CYCLES, ST_SHAPES_EASY, ST_SHAPES_FULL, ST_SHAPES_EASY_FULL, ST_COUNT };
 
 // Per-frame constants
 struct FrameParams {
@@ -162,7 +164,7 @@ struct Work {
     uint32_t *child;        // [levels][N]  : index of the reflected ray in level+1, kNoChild if none
     RayRec *rays;           // [2][N]       : ping-pong ray queues
     uint32_t *counts;       // [levels+1] x kCounterStride : rays per level (see level_count)
-    unsigned long long *stats;  // [ST_COUNT]
+    unsigned long long *stats;  // [ST_COUNT] + [2][kShadeCounts]: RTHIP_COUNTERS=1 - shaded hits per shape and background evaluations, by kernel (0 = k_trace_easy, 1 = k_shade)
     int32_t *id_shape, *id_tri; // [n_pix_slots] primary-hit ids (optional)
     HitSlot *hit;               // [N] per ray of the current level
     uint32_t *redo;             // [N] rays of the current level that must be re-traced by the full kernel
@@ -288,6 +290,7 @@ __device__ __forceinline__ void trace_counters_flush(const FrameParams &fp, cons
         kc.leaves = wave_sum(kc.leaves);
         kc.pops = wave_sum(kc.pops);
         kc.shapes = wave_sum(kc.shapes);
+        kc.shapes_full = wave_sum(kc.shapes_full);
         kc.mesh_hits = wave_sum(kc.mesh_hits);
         kc.wave_steps = wave_sum(kc.wave_steps);
         kc.wave_tris = wave_sum(kc.wave_tris);
@@ -319,6 +322,7 @@ __device__ __forceinline__ void trace_counters_flush(const FrameParams &fp, cons
             atomicAdd(&w.stats[ST_KD_LEAVES], (unsigned long long)kc.leaves);
             atomicAdd(&w.stats[ST_KD_POPS], (unsigned long long)kc.pops);
             atomicAdd(&w.stats[ST_SHAPES], (unsigned long long)kc.shapes);
+            atomicAdd(&w.stats[ST_SHAPES_FULL], (unsigned long long)kc.shapes_full);
             atomicAdd(&w.stats[ST_MESH_HITS], (unsigned long long)kc.mesh_hits);
         }
 }
@@ -334,7 +338,7 @@ __global__ __launch_bounds__(kBlock, RT_TRACE_OCC) void k_trace(SceneView sv, Fr
     KdStack st = make_stack(lds_dyn + threadIdx.x, kBlock, stack_cap, nullptr);
     const uint32_t n = min(w.N, REDO ? w.redo_count[0] : ((level == 0) ? fp.N0 : level_count(w, level)));  // (lists are bounded by the workspace)
     const uint32_t n_shadow = fp.renderer == RTHIP_RENDER_RAYTRACER ? sv.n_lights : 0u;  // DebugRaycaster: closest hit only
-    KdCounters kc = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    KdCounters kc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t max_ray_nodes = 0;
     const long long t_start = COUNT ? clock64() : 0;
     if (!REDO) stage_store(w, w.stage_base + STAGES_PER_LEVEL * level + STAGE_WALK);
@@ -655,6 +659,7 @@ __device__ __forceinline__ int32_t cast_ray(const SceneView &sv, Park park, Stac
             }
             if (COUNT) cnt.shapes++;
             if (type == RTHIP_SHAPE_SPHERE && ball_missed(sh.bound_c[0], sh.bound_c[1], sh.bound_c[2], sh.bound_r2, o, d)) continue;
+            if (COUNT) cnt.shapes_full++;
             V3 lo = xform(sh.inv, o, 1.0);
             V3 ld = normalized(xform(sh.inv, d, 0.0));
             V3 p;
@@ -686,6 +691,7 @@ __device__ __forceinline__ int32_t cast_ray(const SceneView &sv, Park park, Stac
         {
             const V3 o = park.o(), d = park.d();
             if (ball_missed(sh->bound_c[0], sh->bound_c[1], sh->bound_c[2], sh->bound_r2, o, d)) continue;
+            if (COUNT) cnt.shapes_full += (q == 0);
             double inv[12];
 #pragma unroll
             for (int k = 0; k < 12; k++) inv[k] = sh->inv[k];
@@ -805,6 +811,8 @@ __device__ __forceinline__ void shade_and_spawn(const SceneView &sv, const Frame
     so.spawn = false;
     so.shadow_rays = 0;
     if (have) {
+        if (fp.count_kd == 1)  // counting context: what was shaded, for the flop accounting of this kernel (bench.py)
+            atomicAdd(&w.stats[ST_COUNT + (HARD ? 0u : kShadeCounts) + (h.shape < 0 ? kShadeCountShapes : min((uint32_t)h.shape, kShadeCountShapes - 1u))], 1ull);
         if (fp.renderer == RTHIP_RENDER_RAYTRACER) {
             shade_stage(sv, tabs, h, d, level < fp.max_rec, so);
         } else {
@@ -939,6 +947,7 @@ __device__ __forceinline__ int32_t cast_ray(const SceneView &sv, V3 o, V3 d, boo
         if (COUNT) cnt.shapes++;
         const int32_t type = sh->type;
         if (type != RTHIP_SHAPE_PLANE && ball_missed(sh->bound_c[0], sh->bound_c[1], sh->bound_c[2], sh->bound_r2, o, d)) continue;
+        if (COUNT) cnt.shapes_full++;
         double inv[12];
 #pragma unroll
         for (int k = 0; k < 12; k++) inv[k] = sh->inv[k];
@@ -1031,7 +1040,7 @@ __global__ __launch_bounds__(kBlock, RT_EASY_OCC) void k_trace_easy(SceneView sv
     stage_perlin_tables(sv, n_tables);
     const uint32_t n_shadow = fp.renderer == RTHIP_RENDER_RAYTRACER ? sv.n_lights : 0u;  // DebugRaycaster: closest hit only
     const uint32_t lane = threadIdx.x & 63u;
-    KdCounters kc = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    KdCounters kc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t shadow_total = 0, spawn_total = 0;
     const long long t_start = COUNT ? clock64() : 0;
     for (uint32_t base = blockIdx.x * kBlock; base < n; base += gridDim.x * kBlock) {
@@ -1067,7 +1076,11 @@ __global__ __launch_bounds__(kBlock, RT_EASY_OCC) void k_trace_easy(SceneView sv
     shade_stats_flush(w, sh, 0, level, levels, shadow_total, spawn_total);
     if (COUNT) {
         kc.shapes = wave_sum(kc.shapes);
-        if ((threadIdx.x & 63u) == 0 && kc.shapes && fp.count_kd != 2) atomicAdd(&w.stats[ST_SHAPES_EASY], (unsigned long long)kc.shapes);
+        kc.shapes_full = wave_sum(kc.shapes_full);
+        if ((threadIdx.x & 63u) == 0 && kc.shapes && fp.count_kd != 2) {
+            atomicAdd(&w.stats[ST_SHAPES_EASY], (unsigned long long)kc.shapes);
+            atomicAdd(&w.stats[ST_SHAPES_EASY_FULL], (unsigned long long)kc.shapes_full);
+        }
         (void)t_start;
     }
 }
@@ -1086,7 +1099,7 @@ __global__ __launch_bounds__(kBlock, RT_QUAD_OCC) void k_trace_quad(SceneView sv
     park.p = reinterpret_cast<double *>(reinterpret_cast<char *>(lds_dyn) + quad::park_offset(stack_cap) + g * quad::kParkStride);
     const uint32_t n = min(w.N, w.hard_count[0]);
     const uint32_t n_shadow = fp.renderer == RTHIP_RENDER_RAYTRACER ? sv.n_lights : 0u;  // DebugRaycaster: closest hit only
-    KdCounters kc = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    KdCounters kc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t max_ray_nodes = 0;
     const long long t_start = COUNT ? clock64() : 0;
     stage_store(w, w.stage_base + STAGES_PER_LEVEL * level + STAGE_WALK);
@@ -2095,7 +2108,7 @@ static int render_frame(rthip_ctx *c, const rthip_camera *cam, uint32_t n_frames
         if (c->child.ensure(sizeof(uint32_t) * N * levels)) return RTHIP_E_HIP;
         if (c->rays.ensure(sizeof(RayRec) * 2 * N)) return RTHIP_E_HIP;
         if (c->counts.ensure(sizeof(uint32_t) * kCounterSlots * kCounterStride)) return RTHIP_E_HIP;
-        if (c->stats.ensure(sizeof(unsigned long long) * ST_COUNT)) return RTHIP_E_HIP;
+        if (c->stats.ensure(sizeof(unsigned long long) * (ST_COUNT + 2 * kShadeCounts))) return RTHIP_E_HIP;
         c->bs_stride = bs_stride;
         c->bs_levels = levels;
         if (c->block_stats.ensure(sizeof(uint2) * 2 * (size_t)c->bs_stride * levels)) return RTHIP_E_HIP;
@@ -2133,7 +2146,7 @@ static int render_frame(rthip_ctx *c, const rthip_camera *cam, uint32_t n_frames
         w.child = (uint32_t *)take(sizeof(uint32_t) * N * levels);
         w.rays = (RayRec *)take(sizeof(RayRec) * 2 * N);
         w.counts = (uint32_t *)take(sizeof(uint32_t) * kCounterSlots * kCounterStride);
-        w.stats = (unsigned long long *)take(sizeof(unsigned long long) * 2 * ST_COUNT);
+        w.stats = (unsigned long long *)take(sizeof(unsigned long long) * (ST_COUNT + 2 * kShadeCounts));
         w.block_stats = (uint2 *)take(sizeof(uint2) * 2 * (size_t)bs_stride * levels);
         w.hit = (HitSlot *)take(sizeof(HitSlot) * N);
         w.redo = (uint32_t *)take(sizeof(uint32_t) * 2 * N);
@@ -2222,7 +2235,7 @@ static int render_frame(rthip_ctx *c, const rthip_camera *cam, uint32_t n_frames
     bool interrupted = false;
     auto enqueue = [&]() -> int {
     {   // statistics, list counters of the first chunk, the call's cameras: one launch (k_begin)
-        const uint32_t na = 2 * ST_COUNT, nb = (uint32_t)(2 * 2 * (size_t)bs_stride * levels), nc = kCounterSlots * kCounterStride;
+        const uint32_t na = 2 * (ST_COUNT + 2 * kShadeCounts), nb = (uint32_t)(2 * 2 * (size_t)bs_stride * levels), nc = kCounterSlots * kCounterStride;
         const uint32_t most = na > nb ? (na > nc ? na : nc) : (nb > nc ? nb : nc);
         hipLaunchKernelGGL(k_begin, dim3((most + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, (uint32_t *)w.stats, na,
                            (uint32_t *)w.block_stats, nb, w.counts, nc, c->d_cams, n_frames, (const rthip_camera *)c->h_cams, c->d_cam_seq,
@@ -2362,8 +2375,12 @@ static int render_frame(rthip_ctx *c, const rthip_camera *cam, uint32_t n_frames
 
 static int finish_stats(rthip_ctx *c, const rthip_params *p) {
     HIP_TRY(hipStreamSynchronize(c->stream));
-    unsigned long long st[ST_COUNT];
+    unsigned long long st[ST_COUNT + 2 * kShadeCounts];
     HIP_TRY(hipMemcpy(st, c->stats.p, sizeof st, hipMemcpyDeviceToHost));
+    for (uint32_t k = 0; k < 2; k++) {
+        for (uint32_t i = 0; i < kShadeCountShapes; i++) c->last.shape_hits[k][i] = st[ST_COUNT + k * kShadeCounts + i];
+        c->last.background_evals[k] = st[ST_COUNT + k * kShadeCounts + kShadeCountShapes];
+    }
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
     // primary rays = pixels inside the image handled by this part (x9 with SSAA)
@@ -2382,10 +2399,12 @@ static int finish_stats(rthip_ctx *c, const rthip_params *p) {
     {
         std::vector<uint2> parts(2 * (size_t)c->bs_stride * c->bs_levels);
         if (!parts.empty()) HIP_TRY(hipMemcpy(parts.data(), c->block_stats.p, sizeof(uint2) * parts.size(), hipMemcpyDeviceToHost));
-        uint64_t shadow = 0, reflect = 0;
-        for (const uint2 &v : parts) { shadow += v.x; reflect += v.y; }
-        c->last.rays_shadow = shadow;
-        c->last.rays_reflect = reflect;
+        uint64_t shadow[2] = {0, 0}, reflect[2] = {0, 0};  // [0] from k_trace_easy's workgroups, [1] from k_shade's
+        const size_t half = parts.size() / 2;
+        for (size_t i = 0; i < parts.size(); i++) { shadow[i >= half] += parts[i].x; reflect[i >= half] += parts[i].y; }
+        c->last.rays_shadow = shadow[0] + shadow[1];
+        c->last.rays_reflect = reflect[0] + reflect[1];
+        for (int k = 0; k < 2; k++) { c->last.rays_shadow_by_kernel[k] = shadow[k]; c->last.rays_reflect_by_kernel[k] = reflect[k]; }
     }
     c->last.kd_nodes_visited = st[ST_KD_NODES];
     c->last.kd_tris_tested = st[ST_KD_TRIS];
@@ -2401,6 +2420,8 @@ static int finish_stats(rthip_ctx *c, const rthip_params *p) {
     c->last.wave_cycles_max = st[ST_WAVE_CYCLES_MAX];
     c->last.fetch_cycles = st[ST_FETCH_CYCLES];
     c->last.shape_tests_easy = st[ST_SHAPES_EASY];
+    c->last.shape_tests_full = st[ST_SHAPES_FULL];
+    c->last.shape_tests_easy_full = st[ST_SHAPES_EASY_FULL];
     {
         std::vector<uint32_t> all(kCounterSlots * kCounterStride);
         HIP_TRY(hipMemcpy(all.data(), c->counts.p, sizeof(uint32_t) * all.size(), hipMemcpyDeviceToHost));

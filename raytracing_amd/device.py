@@ -48,7 +48,10 @@ class Stats(C.Structure):
                 ("wave_cycles_max", C.c_uint64), ("fetch_cycles", C.c_uint64),
                 ("level_rays", C.c_uint32 * 17), ("level_ms_trace", C.c_float * 17), ("level_ms_shade", C.c_float * 17), ("level_ms_easy", C.c_float * 17),
                 ("ms_easy", C.c_float), ("rays_redo", C.c_uint32), ("rays_hard", C.c_uint64), ("shape_tests_easy", C.c_uint64),
-                ("graphs_captured", C.c_uint32), ("graph_replays", C.c_uint32)]
+                ("graphs_captured", C.c_uint32), ("graph_replays", C.c_uint32),
+                ("shape_hits", (C.c_uint64 * 64) * 2), ("background_evals", C.c_uint64 * 2),
+                ("rays_shadow_by_kernel", C.c_uint64 * 2), ("rays_reflect_by_kernel", C.c_uint64 * 2),
+                ("shape_tests_full", C.c_uint64), ("shape_tests_easy_full", C.c_uint64)]
 
 
 class Mesh(C.Structure):  # rthip_mesh
@@ -78,6 +81,30 @@ class SceneDesc(C.Structure):  # rthip_scene_desc (tests build variants of a fla
 class UploadInfo(C.Structure):  # rthip_upload_info
     _fields_ = [("kd_meshes", C.c_uint32), ("kd_nodes", C.c_uint32), ("kd_levels", C.c_uint32), ("pad", C.c_uint32), ("kd_refs", C.c_uint64),
                 ("kd_device_ms", C.c_float), ("bvh_meshes", C.c_uint32), ("bvh_nodes", C.c_uint32), ("upload_ms", C.c_float)]
+
+
+class Shape(C.Structure):  # rthip_shape
+    _fields_ = [("type", C.c_int32), ("material", C.c_int32), ("mesh", C.c_int32), ("shape_id", C.c_uint32), ("inv", C.c_double * 12),
+                ("fwd", C.c_double * 12), ("nrm", C.c_double * 12), ("plane_n", C.c_double * 4), ("rt_lin", C.c_double), ("rt_t", C.c_double),
+                ("bound_c", C.c_double * 3), ("bound_r2", C.c_double)]
+
+
+class MatOp(C.Structure):  # rthip_matop
+    _fields_ = [("op", C.c_int32), ("noise", C.c_int32), ("first_op", C.c_int32), ("pad", C.c_int32), ("color", C.c_double * 3), ("absorptance", C.c_double)]
+
+
+class Noise(C.Structure):  # rthip_noise
+    _fields_ = [("type", C.c_int32), ("table", C.c_int32), ("points_base", C.c_int32), ("divisions", C.c_int32), ("octaves", C.c_uint32), ("pad", C.c_int32),
+                ("domain", C.c_double), ("persistance", C.c_double), ("step", C.c_double), ("frequency", C.c_double), ("turbolence", C.c_double)]
+
+
+def scene_tables(desc_ptr):
+    """(shapes, material ops, noises, background type) of a flattened scene as ctypes arrays (views into the caller's memory)"""
+    d = SceneDesc.from_address(desc_ptr)
+    shapes = (Shape * d.n_shapes).from_address(d.shapes) if d.n_shapes else []
+    mats = (MatOp * d.n_materials).from_address(d.materials) if d.n_materials else []
+    noises = (Noise * d.n_noises).from_address(d.noises) if d.n_noises else []
+    return shapes, mats, noises, d.background.type
 
 
 class RthipError(RuntimeError):

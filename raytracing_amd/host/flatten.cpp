@@ -299,7 +299,30 @@ struct Flattener {
         d.attenuation = l.Attenuation;
         return d;
     }
+    // triangles of every distinct mesh below `node` (the geometry arrays are reserved once: five 2 M-triangle meshes appended to
+    // vectors that regrow copied gigabytes)
+    static void CountTriangles(SceneNode *node, std::map<const Mesh *, size_t> &seen) {
+        if (auto shape = node->GetComponentOfType<Shape>())
+            if (auto mesh = dynamic_cast<Mesh *>(shape.get())) seen[mesh] = mesh->GetTriangles().size();
+        for (auto &child : node->GetChildren()) CountTriangles(child.get(), seen);
+    }
     int Run() {
+        if (!previous) {
+            std::map<const Mesh *, size_t> seen;
+            CountTriangles(scene->GetRoot().get(), seen);
+            size_t total = 0, total_host_bvh = 0;
+            bool any_device_kd = false;
+            for (auto &kv : seen) {
+                total += kv.second;
+                if (!kv.first->BvhBuiltOnDevice()) total_host_bvh += kv.second;
+                any_device_kd = any_device_kd || (kv.first->KdBuiltOnDevice() && kv.second);
+            }
+            out.tris.reserve(total);
+            out.tri_normals.reserve(9 * total);
+            if (any_device_kd) out.tri_verts.reserve(9 * total);
+            out.bvh_tris.reserve(total_host_bvh);
+            out.bvh_tri_index.reserve(total_host_bvh);
+        }
         int rc = Walk(scene->GetRoot().get());
         if (rc) return rc;
         for (auto &l : scene->Lights) {

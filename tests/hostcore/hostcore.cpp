@@ -43,7 +43,7 @@ int hc_render(const rthip_scene_desc *scene, const rthip_camera *cam, const rthi
         float stack_t[128];
         KdStack st = make_stack(stack_mem, 1, 128, stack_t);
         uint64_t mine = 0;
-        KdCounters kc = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        KdCounters kc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         for (;;) {
             uint32_t y = next.fetch_add(1);
             if (y >= p->height) break;

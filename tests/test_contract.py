@@ -43,7 +43,7 @@ def test_bench_refuses_a_world_size_that_is_not_gpus():
 
 @pytest.mark.gpu
 def test_bench_line_keeps_the_contract():
-    r = _run_bench("--steps", "24", "--warmup", "8", "--no-cpu-baseline", "--no-config4")
+    r = _run_bench("--steps", "24", "--warmup", "8", "--no-cpu-baseline", "--no-config4", "--no-config5")
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
@@ -69,7 +69,15 @@ def test_bench_line_keeps_the_contract():
     assert rf["avg_launch_ms"] > 0 and rf["launches_per_call"] == 4 and rf["avg_launch_ms_calls_in_flight"] >= 0.8 * rf["avg_launch_ms"]
     w, c = rf["flop_weights"], rf["counts_per_call_rank0"]
     assert rf["algorithmic_flops_per_call_rank0"] == (w["bvh_step_4_boxes_fp32"] * c["bvh_steps"] + w["triangle_test_fp64"] * c["triangle_tests"]
-                                                      + w["shape_entry_fp64"] * c["shape_entries"] + w["hit_record_fp64"] * c["rays"])
+                                                      + w["shape_entry_fp64"] * c["shape_entries"] + w["hit_record_fp64"] * c["rays"]
+                                                      + w["shape_entry_rejected_by_ball_test"] * c["shape_entries_rejected_by_ball_test"])
+    # every ray kernel of the timed regime has its own roofline entry
+    assert {k["kernel"] for k in rf["kernels"]} == {"k_trace_quad", "k_trace_easy", "k_shade"}
+    assert all(k["algorithmic_flops_per_call"] > 0 and k["ms_per_call"] > 0 and 0 < k["frac"] < 1 for k in rf["kernels"])
+    # the other BASELINE configs are in the line (config 5 is left to the driver's run: ~40 s of scene construction)
+    for name in ("config2", "config3_closeup"):
+        o = d[name]
+        assert o["rays_per_frame"] > 4_000_000 and 0.1 < o["ms_per_frame"] < 50 and 0 < o["roofline"]["frac"] < 1
     # RenderSync's contract is in the line by default: a lone frame, and the frame handed back in host memory
     assert 0.1 < d["config"]["single_frame_latency_ms"] < 50
     assert d["config"]["single_frame_latency_ms"] <= d["config"]["ms_per_frame_with_d2h"] * 1.2 < 100
@@ -87,7 +95,7 @@ def test_bench_multi_rank_control_flow_on_one_gpu():
     """bench.py under torch.distributed.run with two ranks that share GPU 0 and exchange over gloo (RCCL refuses two ranks
     on one device): the N > 1 branch of the script end to end — tile partition, per-rank ray counts summed, gather to
     rank 0, device assemble.  The assembled frame is the single-GPU frame; the throughput it prints is not a measurement."""
-    one = _run_bench("--steps", "8", "--warmup", "8", "--no-cpu-baseline", "--no-config4", "--repeats", "1")
+    one = _run_bench("--steps", "8", "--warmup", "8", "--no-cpu-baseline", "--no-config4", "--no-other-configs", "--repeats", "1")
     assert one.returncode == 0, one.stderr[-2000:]
     ref = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][0])
     # no launcher on the command line: bench.py starts its two ranks itself (the driver's command is `python bench.py --gpus N ...`)
