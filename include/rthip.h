@@ -330,6 +330,12 @@ int rthip_update_scene(rthip_ctx *ctx, const rthip_scene_desc *scene);
 int rthip_render(rthip_ctx *ctx, const rthip_camera *cam, const rthip_params *params,
                  uint32_t *out_pixels, int32_t *out_shape_id, int32_t *out_tri_index);
 
+/* rthip_render for a run of frames: n_frames (1..RTHIP_MAX_BATCH) cameras over the same scene traced as one set of launches
+ * (rthip_render_batch_device), then ONE device-to-host copy; out_pixels receives the frames one after the other
+ * (width*height uint32 each).  Whole frames only (part_count = 1), no id images.
+ * replaces: the frame-after-frame RenderSync loop over a camera path known ahead (Sandbox/Sandbox.cpp:315-359). */
+int rthip_render_batch(rthip_ctx *ctx, const rthip_camera *cams, uint32_t n_frames, const rthip_params *params, uint32_t *out_pixels);
+
 /* Page-locked host memory (hipHostMalloc) for a buffer the caller keeps passing as out_pixels, so that the
  * device-to-host copy of rthip_render runs at PCIe rate instead of through the runtime's staging buffers.
  * replaces: the `new unsigned[w * h]` of the renderer-owned m_Pixels (Raytracer.cpp:20-25), which every Render
@@ -409,6 +415,13 @@ int rthip_multi_upload_scene(rthip_multi *m, const rthip_scene_desc *scene, uint
 /* one frame into host memory (width*height uint32, as rthip_render); params->part_* / layout are set by the call;
  * out_stats (nullable): ray counts summed over the devices, ms_total = the slowest device's */
 int rthip_multi_render(rthip_multi *m, const rthip_camera *cam, const rthip_params *params, uint32_t *out_pixels, rthip_stats *out_stats);
+/* a run of frames (1..RTHIP_MAX_BATCH cameras) split over the devices in ONE round: each device traces its tiles of all the frames
+ * as one set of launches, the parts cross xGMI once, one assemble, one device-to-host copy of n_frames * width*height uint32 into
+ * out_pixels, one synchronisation (statistics are summed over devices and frames).  A device's share of a single frame is
+ * latency-bound; a run gives every device whole frames' worth of rays per launch.
+ * replaces: the worker pool of AbstractRaycaster::Render (Raytracer.cpp:52-87) for a queued camera path */
+int rthip_multi_render_batch(rthip_multi *m, const rthip_camera *cams, uint32_t n_frames, const rthip_params *params, uint32_t *out_pixels,
+                             rthip_stats *out_stats);
 float rthip_multi_progress(rthip_multi *m);
 int rthip_multi_interrupt(rthip_multi *m);
 

@@ -2527,6 +2527,26 @@ int rthip_render(rthip_ctx *c, const rthip_camera *cam, const rthip_params *p, u
     return 0;
 }
 
+int rthip_render_batch(rthip_ctx *c, const rthip_camera *cams, uint32_t n_frames, const rthip_params *p, uint32_t *out_pixels) {
+    if (!c || !out_pixels) return fail(RTHIP_E_INVALID, "rthip_render_batch: null argument");
+    int rc = check_params(cams, p);
+    if (rc) return rc;
+    if (n_frames == 0 || n_frames > RTHIP_MAX_BATCH) return fail(RTHIP_E_INVALID, "rthip_render_batch: %u frames per call, limit %d", n_frames, RTHIP_MAX_BATCH);
+    if (p->part_count != 1) return fail(RTHIP_E_INVALID, "rthip_render_batch: whole frames only (part_count = 1)");
+    if (set_device(c)) return RTHIP_E_HIP;
+    const size_t npx = (size_t)p->width * p->height * n_frames;
+    if (c->pixels_tmp.ensure(sizeof(uint32_t) * npx)) return RTHIP_E_HIP;
+    rthip_params pf = *p;
+    pf.layout = 0;
+    rc = render_frame(c, cams, n_frames, &pf, (uint32_t *)c->pixels_tmp.p, nullptr, nullptr);
+    if (rc) return rc;
+    rc = finish_stats(c, p);
+    if (rc) return rc;
+    if (c->interrupt.load()) return fail(RTHIP_E_INTERRUPTED, "rthip_render_batch: interrupted");
+    HIP_TRY(hipMemcpy(out_pixels, c->pixels_tmp.p, sizeof(uint32_t) * npx, hipMemcpyDeviceToHost));
+    return 0;
+}
+
 int rthip_host_alloc(rthip_ctx *c, size_t bytes, void **out) {
     if (!c || !out || !bytes) return fail(RTHIP_E_INVALID, "rthip_host_alloc: null argument");
     *out = nullptr;

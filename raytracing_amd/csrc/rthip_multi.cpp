@@ -219,15 +219,26 @@ static int ensure(void **p, size_t *cap, size_t bytes) {
 }
 
 int rthip_multi_render(rthip_multi *m, const rthip_camera *cam, const rthip_params *params, uint32_t *out_pixels, rthip_stats *out_stats) {
+    return rthip_multi_render_batch(m, cam, 1, params, out_pixels, out_stats);
+}
+
+// n_frames cameras in ONE round: every device traces its tiles of all the frames as one set of launches
+// (rthip_render_batch_device), the parts of the whole run cross xGMI once (one send / receive per peer), one assemble launch,
+// one device-to-host copy, one synchronisation at the end.  A device's share of a single 1080p frame is latency-bound (an
+// eighth of a frame takes almost half the time of the whole frame); a run of frames gives every device whole frames' worth of
+// rays per launch.
+int rthip_multi_render_batch(rthip_multi *m, const rthip_camera *cam, uint32_t n_frames, const rthip_params *params, uint32_t *out_pixels,
+                             rthip_stats *out_stats) {
     if (!m || !cam || !params || !out_pixels) return mfail(RTHIP_E_INVALID, "rthip_multi_render: null argument");
+    if (n_frames == 0 || n_frames > RTHIP_MAX_BATCH) return mfail(RTHIP_E_INVALID, "rthip_multi_render_batch: %u frames per call, limit %d", n_frames, RTHIP_MAX_BATCH);
     const int n = (int)m->devices.size();
     rthip_params prm = *params;
     prm.part_count = (uint32_t)n;
     prm.part_index = 0;
     prm.layout = 1;
-    const size_t part_px = (size_t)rthip_part_pixels(&prm);
+    const size_t part_px = (size_t)rthip_part_pixels(&prm) * n_frames;  // a device's part of the whole run: frame after frame
     if (!part_px) return mfail(RTHIP_E_INVALID, "rthip_multi_render: bad frame size %ux%u", params->width, params->height);
-    const size_t part_bytes = part_px * sizeof(uint32_t), frame_px = (size_t)params->width * params->height;
+    const size_t part_bytes = part_px * sizeof(uint32_t), frame_px = (size_t)params->width * params->height * n_frames;
     MHIP(hipSetDevice(m->devices[0]));
     int rc;
     if ((rc = ensure((void **)&m->gathered, &m->gathered_cap, part_bytes * n))) return rc;
@@ -244,7 +255,7 @@ int rthip_multi_render(rthip_multi *m, const rthip_camera *cam, const rthip_para
     // every device: its interleaved tiles, asynchronously on its own stream
     for (int i = 0; i < n; i++) {
         prm.part_index = (uint32_t)i;
-        if ((rc = rthip_render_device(m->ctx[i], cam, &prm, m->part[i], 0))) return rc;
+        if ((rc = rthip_render_batch_device(m->ctx[i], cam, n_frames, &prm, m->part[i], 0))) return rc;
         MHIP(hipSetDevice(m->devices[i]));
         MHIP(hipEventRecord(m->rendered[i], (hipStream_t)rthip_stream(m->ctx[i])));
     }
@@ -276,7 +287,7 @@ int rthip_multi_render(rthip_multi *m, const rthip_camera *cam, const rthip_para
         }
     }
     prm.part_index = 0;
-    if ((rc = rthip_assemble(m->ctx[0], &prm, m->gathered, m->frame, 0))) return rc;
+    if ((rc = rthip_assemble_batch(m->ctx[0], &prm, n_frames, m->gathered, m->frame, 0))) return rc;  // [part][frame][slot] -> frames
     rthip_stats sum;
     memset(&sum, 0, sizeof sum);
     int interrupted = 0;

@@ -22,7 +22,7 @@ SYMBOLS = ["rthip_create", "rthip_destroy", "rthip_last_error", "rthip_upload_sc
            "rthip_host_free", "rthip_update_scene", "rthip_render_device_noalloc", "rthip_collect_stats", "rthip_multi_create",
            "rthip_multi_destroy", "rthip_multi_device_count", "rthip_multi_context", "rthip_multi_transport", "rthip_multi_upload_scene",
            "rthip_multi_render", "rthip_multi_progress", "rthip_multi_interrupt", "rthip_upload_scene_ex", "rthip_probe_bvh",
-           "rthip_debug_device_allocs", "rthip_probe_kd", "rthip_get_upload_info"]
+           "rthip_debug_device_allocs", "rthip_probe_kd", "rthip_get_upload_info", "rthip_render_batch", "rthip_multi_render_batch"]
 MAX_BATCH = 64  # RTHIP_MAX_BATCH
 UPLOAD_BUILD_BVH, UPLOAD_KEEP_GEOMETRY, UPLOAD_BUILD_KD = 1, 2, 4  # RTHIP_UPLOAD_*
 
@@ -157,6 +157,8 @@ def lib():
     L.rthip_multi_transport.restype = C.c_char_p
     L.rthip_multi_upload_scene.argtypes = [vp, vp, C.c_uint32]
     L.rthip_multi_render.argtypes = [vp, C.POINTER(Camera), C.POINTER(Params), c_u32p, C.POINTER(Stats)]
+    L.rthip_multi_render_batch.argtypes = [vp, C.POINTER(Camera), C.c_uint32, C.POINTER(Params), c_u32p, C.POINTER(Stats)]
+    L.rthip_render_batch.argtypes = [vp, C.POINTER(Camera), C.c_uint32, C.POINTER(Params), c_u32p]
     L.rthip_multi_progress.argtypes = [vp]
     L.rthip_multi_progress.restype = C.c_float
     L.rthip_multi_interrupt.argtypes = [vp]
@@ -269,6 +271,13 @@ class Context:
         assert px.size == n
         return {"pixels": px, "shape": sh, "tri": tr}
 
+    def render_batch(self, cams, params):
+        """rthip_render_batch: a run of frames into host memory -> [n, height, width] uint32"""
+        arr = cams if isinstance(cams, C.Array) else (Camera * len(cams))(*cams)
+        px = np.zeros((len(arr), params.height, params.width), np.uint32)
+        self._check(self.L.rthip_render_batch(self.h, arr, len(arr), C.byref(params), px.ctypes.data_as(c_u32p)))
+        return px
+
     def render_device(self, cam, params, d_pixels_ptr, sync=False):
         self._check(self.L.rthip_render_device(self.h, C.byref(cam), C.byref(params), C.c_void_p(d_pixels_ptr), int(sync)))
 
@@ -373,6 +382,14 @@ class MultiContext:
         px = np.zeros((params.height, params.width), np.uint32)
         st = Stats()
         self._check(self.L.rthip_multi_render(self.h, C.byref(cam), C.byref(params), px.ctypes.data_as(c_u32p), C.byref(st)))
+        return {"pixels": px, "rays": st.rays_primary + st.rays_shadow + st.rays_reflect, "stats": st}
+
+    def render_batch(self, cams, params):
+        """a run of frames in one round over the devices -> [n, height, width] uint32"""
+        arr = cams if isinstance(cams, C.Array) else (Camera * len(cams))(*cams)
+        px = np.zeros((len(arr), params.height, params.width), np.uint32)
+        st = Stats()
+        self._check(self.L.rthip_multi_render_batch(self.h, arr, len(arr), C.byref(params), px.ctypes.data_as(c_u32p), C.byref(st)))
         return {"pixels": px, "rays": st.rays_primary + st.rays_shadow + st.rays_reflect, "stats": st}
 
     def close(self):

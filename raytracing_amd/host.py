@@ -43,6 +43,7 @@ def load_host():
         L.rehost_write_ppm.argtypes = [C.c_char_p, C.c_void_p, C.c_int, C.c_int]
         L.rehost_render_moved.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.POINTER(C.c_int)]
         L.rehost_render_flip_normal_mode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
+        L.rehost_render_path.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         _host = sb
     return _host
 
@@ -118,6 +119,18 @@ class HostScene:
         if rc != 0:
             raise RuntimeError(f"rehost_render_moved failed ({rc}): " + self.L.rehost_last_error().decode())
         return px, bool(kept.value)
+
+    def render_path(self, width, height, poses, max_recursion=3, aa=0):
+        """HipRaytracer::RenderPathSync: one frame per (position, direction) pose of `poses` ([n, 6]) over the scene as it is, traced
+        in runs (over the GPUs of set_devices, if any) -> [n, height, width] uint32"""
+        from .sbapi import RenderParams
+        poses = np.ascontiguousarray(poses, dtype=np.float64).reshape(-1, 6)
+        p = RenderParams(width, height, 0.0, max_recursion, aa, 8, 0)
+        px = np.zeros((len(poses), height, width), np.uint32)
+        rc = self.L.rehost_render_path(self.h, C.byref(p), len(poses), poses.ctypes.data_as(C.c_void_p), px.ctypes.data_as(C.c_void_p))
+        if rc != 0:
+            raise RuntimeError(f"rehost_render_path failed ({rc}): " + self.L.rehost_last_error().decode())
+        return px
 
     def render_flip_normal_mode(self, width, height, max_recursion=3):
         """Two frames through ONE HipRaytracer; between them Mesh::NormalMode of every mesh flips (Face <-> Vertex).  Returns

@@ -439,12 +439,15 @@ void FlatScene::ReleaseGeometry() {
 }
 
 void MakeCamera(const Scene *scene, size_t width, size_t height, real fovY, rthip_camera &cam) {
-    const Vector3 forward = scene->Camera.Direction.Normalized();
+    MakeCamera(scene->Camera.Position, scene->Camera.Direction, width, height, fovY, cam);
+}
+void MakeCamera(const Vector3 &position, const Vector3 &direction, size_t width, size_t height, real fovY, rthip_camera &cam) {
+    const Vector3 forward = direction.Normalized();
     const Vector3 right = Cross(forward, Vector3::Up).Normalized();
     const Vector3 up = Cross(right, forward).Normalized();
     const real h2 = std::atan(fovY / 2);  // atan, not tan (Raytracer.cpp:109)
     const real w2 = h2 * (real)width / (real)height;
-    const Vector3 &p = scene->Camera.Position;
+    const Vector3 &p = position;
     cam.position[0] = p.X; cam.position[1] = p.Y; cam.position[2] = p.Z;
     cam.forward[0] = forward.X; cam.forward[1] = forward.Y; cam.forward[2] = forward.Z;
     cam.right[0] = right.X; cam.right[1] = right.Y; cam.right[2] = right.Z;

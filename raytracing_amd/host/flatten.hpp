@@ -56,5 +56,6 @@ inline uint32_t UploadFlags(const FlatScene &f) {
 void ForceHostBvhEverywhere(SceneNode *node);
 
 void MakeCamera(const Scene *scene, size_t width, size_t height, real fovY, rthip_camera &cam);
+void MakeCamera(const Vector3 &position, const Vector3 &direction, size_t width, size_t height, real fovY, rthip_camera &cam);
 
 }  // namespace re

@@ -37,6 +37,7 @@ HipRaytracer::~HipRaytracer() {
         else if (m_Busy && m_Ctx) rthip_interrupt(m_Ctx);
         m_Idle.wait(lock, [this] { return !m_Busy; });
     }
+    if (m_Ctx && m_PathFrames) (void)rthip_host_free(m_Ctx, m_PathFrames);
     if (m_Ctx && m_PixelsPinned) {  // m_Pixels is page-locked memory of the library, not the base class's new[]
         (void)rthip_host_free(m_Ctx, m_Pixels);
         m_Pixels = nullptr;
@@ -85,38 +86,41 @@ void HipRaytracer::Render(Scene *scene, std::promise<RenderStatus> p) {
     }
     m_Finished = false;  // m_Status = { false, false, 0, m_Pixels }, Raytracer.cpp:36
     m_Interrupted = false;
-    {   // First Render: the device context, and m_Pixels moves to page-locked memory so that the copy back of every
-        // frame runs at PCIe rate (1080p: 0.18 instead of 0.50 ms).  Done here, on the caller's thread, because the
-        // pixel buffer may only change hands at a Render call (RenderStatus.Pixels is valid until the next Render);
-        // a failure is reported through the promise by the render thread.
+    {
         std::lock_guard<std::mutex> lock(m_Mutex);
-        if (!m_Ctx) {
-            if (Devices.size() > 1) {
-                m_CreateRc = rthip_multi_create(Devices.data(), (int)Devices.size(), &m_Multi);
-                if (!m_CreateRc) m_Ctx = rthip_multi_context(m_Multi, 0);
-            } else {
-                m_CreateRc = rthip_create(Devices.empty() ? Device : Devices[0], &m_Ctx);
-            }
-            m_CreateErr = m_CreateRc ? rthip_last_error() : "";
-            void *pinned = nullptr;
-            if (!m_CreateRc && rthip_host_alloc(m_Ctx, sizeof(unsigned int) * m_ViewWidth * m_ViewHeight, &pinned) == 0) {
-                delete[] m_Pixels;
-                m_Pixels = static_cast<unsigned int *>(pinned);
-                m_PixelsPinned = true;
-            }
-        }
+        EnsureContext();
     }
     std::thread th(&HipRaytracer::RenderThread, this, scene, std::move(p));
     th.detach();  // Raytracer.cpp:84-87
 }
 
-void HipRaytracer::RenderThread(Scene *scene, std::promise<RenderStatus> p) {
+// First Render: the device context, and m_Pixels moves to page-locked memory so that the copy back of every frame runs at PCIe
+// rate (1080p: 0.18 instead of 0.50 ms).  Done on the caller's thread, because the pixel buffer may only change hands at a
+// Render call (RenderStatus.Pixels is valid until the next Render); a failure is reported through the promise by the render
+// thread.
+void HipRaytracer::EnsureContext() {
+    if (m_Ctx) return;
+    if (Devices.size() > 1) {
+        m_CreateRc = rthip_multi_create(Devices.data(), (int)Devices.size(), &m_Multi);
+        if (!m_CreateRc) m_Ctx = rthip_multi_context(m_Multi, 0);
+    } else {
+        m_CreateRc = rthip_create(Devices.empty() ? Device : Devices[0], &m_Ctx);
+    }
+    m_CreateErr = m_CreateRc ? rthip_last_error() : "";
+    void *pinned = nullptr;
+    if (!m_CreateRc && rthip_host_alloc(m_Ctx, sizeof(unsigned int) * m_ViewWidth * m_ViewHeight, &pinned) == 0) {
+        delete[] m_Pixels;
+        m_Pixels = static_cast<unsigned int *>(pinned);
+        m_PixelsPinned = true;
+    }
+}
+
+// Scene::Compile (Raytracer.cpp:42), flatten, upload - or, when the meshes are the ones already on the device, only the small tables
+int HipRaytracer::PrepareScene(Scene *scene, HipRenderStats &stats, std::string &err) {
     using clock = std::chrono::steady_clock;
     auto ms = [](clock::time_point a, clock::time_point b) { return std::chrono::duration<float, std::milli>(b - a).count(); };
     int rc = 0;
-    std::string err;
-    HipRenderStats stats;
-    try {
+    {
         auto t0 = clock::now();
         scene->Compile();  // Raytracer.cpp:42
         // m_Flat describes what the device holds (geometry arrays released): if the meshes are still the same objects
@@ -153,21 +157,94 @@ void HipRaytracer::RenderThread(Scene *scene, std::promise<RenderStatus> p) {
         }
         auto t2 = clock::now();
         stats.UploadMs = ms(t1, t2);
+    }
+    return rc;
+}
+
+static void FillParams(rthip_params &prm, size_t w, size_t h, unsigned max_recursion, bool ssaa, int renderer, unsigned part_index, unsigned part_count,
+                       unsigned tile_w, unsigned tile_h, bool use_kd) {
+    prm.width = (uint32_t)w;
+    prm.height = (uint32_t)h;
+    prm.max_recursion = max_recursion;
+    prm.aa_mode = ssaa ? 1 : 0;
+    prm.renderer = renderer;
+    prm.part_index = part_index;
+    prm.part_count = part_count;
+    prm.tile_w = tile_w;
+    prm.tile_h = tile_h;
+    prm.layout = 0;
+    prm.accel = use_kd ? 1 : 0;
+}
+
+const unsigned int *HipRaytracer::RenderPathSync(Scene *scene, const std::vector<CameraPose> &path) {
+    {
+        std::unique_lock<std::mutex> lock(m_Mutex);
+        m_Idle.wait(lock, [this] { return !m_Busy; });
+        m_Busy = true;
+        EnsureContext();
+    }
+    m_Finished = false;
+    m_Interrupted = false;
+    int rc = 0;
+    std::string err;
+    HipRenderStats stats;
+    const size_t frame_px = m_ViewWidth * m_ViewHeight;
+    try {
+        rc = PrepareScene(scene, stats, err);
+        if (!rc && path.size() * frame_px > m_PathCapacity) {
+            if (m_PathFrames) (void)rthip_host_free(m_Ctx, m_PathFrames);
+            m_PathFrames = nullptr;
+            m_PathCapacity = 0;
+            void *pinned = nullptr;
+            rc = rthip_host_alloc(m_Ctx, sizeof(unsigned int) * path.size() * frame_px, &pinned);
+            if (rc) err = rthip_last_error();
+            else { m_PathFrames = static_cast<unsigned int *>(pinned); m_PathCapacity = path.size() * frame_px; }
+        }
+        rthip_params prm;
+        FillParams(prm, m_ViewWidth, m_ViewHeight, MaxRecursion, Antialiasing == AAMode::SSAA, RendererKind(), 0, 1, TileWidth, TileHeight, UseReferenceKdTree);
+        std::vector<rthip_camera> cams;
+        for (size_t f0 = 0; !rc && !m_Interrupted && f0 < path.size(); f0 += RTHIP_MAX_BATCH) {
+            const size_t nf = std::min<size_t>(RTHIP_MAX_BATCH, path.size() - f0);
+            cams.resize(nf);
+            for (size_t k = 0; k < nf; k++) MakeCamera(path[f0 + k].Position, path[f0 + k].Direction, m_ViewWidth, m_ViewHeight, m_FoVY, cams[k]);
+            rthip_stats st;
+            std::memset(&st, 0, sizeof st);
+            if (m_Multi) rc = rthip_multi_render_batch(m_Multi, cams.data(), (uint32_t)nf, &prm, m_PathFrames + f0 * frame_px, &st);
+            else rc = rthip_render_batch(m_Ctx, cams.data(), (uint32_t)nf, &prm, m_PathFrames + f0 * frame_px);
+            if (rc == RTHIP_E_INTERRUPTED) { m_Interrupted = true; rc = 0; break; }
+            if (rc) { err = rthip_last_error(); break; }
+            if (m_Multi || rthip_get_stats(m_Ctx, &st) == 0) {
+                stats.RaysPrimary += st.rays_primary; stats.RaysShadow += st.rays_shadow; stats.RaysReflect += st.rays_reflect;
+                stats.Pixels += st.pixels; stats.DeviceMs += st.ms_total;
+            }
+        }
+    } catch (const std::exception &e) {
+        rc = RTHIP_E_INVALID;
+        err = e.what();
+    }
+    m_Finished = true;
+    {
+        std::lock_guard<std::mutex> lock(m_Mutex);
+        m_Stats = stats;
+        m_Busy = false;
+        m_Idle.notify_all();
+    }
+    if (rc) throw DeviceError(rc, err);
+    return m_Interrupted ? nullptr : m_PathFrames;
+}
+
+void HipRaytracer::RenderThread(Scene *scene, std::promise<RenderStatus> p) {
+    int rc = 0;
+    std::string err;
+    HipRenderStats stats;
+    try {
+        rc = PrepareScene(scene, stats, err);
         if (!rc && !m_Interrupted) {
             rthip_camera cam;
             MakeCamera(scene, m_ViewWidth, m_ViewHeight, m_FoVY, cam);
             rthip_params prm;
-            prm.width = (uint32_t)m_ViewWidth;
-            prm.height = (uint32_t)m_ViewHeight;
-            prm.max_recursion = MaxRecursion;
-            prm.aa_mode = Antialiasing == AAMode::SSAA ? 1 : 0;
-            prm.renderer = RendererKind();
-            prm.part_index = PartIndex;
-            prm.part_count = PartCount;
-            prm.tile_w = TileWidth;
-            prm.tile_h = TileHeight;
-            prm.layout = 0;
-            prm.accel = UseReferenceKdTree ? 1 : 0;
+            FillParams(prm, m_ViewWidth, m_ViewHeight, MaxRecursion, Antialiasing == AAMode::SSAA, RendererKind(), PartIndex, PartCount, TileWidth, TileHeight,
+                       UseReferenceKdTree);
             rthip_stats st;
             std::memset(&st, 0, sizeof st);
             if (m_Multi) rc = rthip_multi_render(m_Multi, &cam, &prm, m_Pixels, &st);

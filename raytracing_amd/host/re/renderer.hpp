@@ -73,6 +73,10 @@ struct HipRenderStats {
     bool GeometryKept = false;  // the meshes were the ones already on the device: only the small tables went up
 };
 
+struct CameraPose {  // Scene::Camera's two fields (Scene.h:80-86): one stop of a camera path
+    Vector3 Position, Direction;
+};
+
 class HipRaytracer : public AbstractRaycaster {  // drop-in for re::Raytracer (Raytracer.h:100-116)
 public:
     unsigned int MaxRecursion = 3;
@@ -90,6 +94,13 @@ public:
     ~HipRaytracer() override;
 
     void Render(Scene *scene, std::promise<RenderStatus> p) override;
+    // additive: a QUEUED CAMERA PATH - one frame per pose over the otherwise unchanged scene (what the Sandbox preview renders
+    // frame after frame with RenderSync, Sandbox/Sandbox.cpp:315-359, when the path is known ahead).  Synchronous; the frames are
+    // traced in runs of up to 64 as one set of launches each (rthip_render_batch / rthip_multi_render_batch: with several
+    // Devices every GPU traces its tiles of the whole run and the parts cross xGMI once per run) and returned one after the
+    // other (width*height pixels each, as RenderSync returns one) in a buffer the renderer owns until the next call.
+    // Throws DeviceError like RenderSync; an Interrupt() abandons the path and returns nullptr.
+    const unsigned int *RenderPathSync(Scene *scene, const std::vector<CameraPose> &path);
     void Interrupt() override;
     RenderStatus GetStatus() override;
     HipRenderStats GetLastStats();
@@ -99,6 +110,10 @@ protected:
     virtual int RendererKind() const { return 0; }  // RTHIP_RENDER_RAYTRACER
 private:
     void RenderThread(Scene *scene, std::promise<RenderStatus> p);
+    void EnsureContext();   // first Render: the device context(s), m_Pixels moved to page-locked memory (m_Mutex held)
+    int PrepareScene(Scene *scene, HipRenderStats &stats, std::string &err);  // Compile + flatten + upload (render thread)
+    unsigned int *m_PathFrames = nullptr;  // page-locked, RenderPathSync
+    size_t m_PathCapacity = 0;
     rthip_ctx *m_Ctx = nullptr;      // single device; with Devices.size() > 1: the first device's context (owned by m_Multi)
     rthip_multi *m_Multi = nullptr;
     bool m_PixelsPinned = false;

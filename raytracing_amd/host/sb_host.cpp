@@ -395,6 +395,34 @@ int rehost_render_moved(sb_scene *s, const sb_render_params *p, double dx, uint3
     }
 }
 
+// A queued camera path through ONE renderer (HipRaytracer::RenderPathSync): n poses (position xyz, direction xyz each) over the
+// scene as it is; frames come back one after the other.  `devices` as for sb_render (rehost_set_devices).
+int rehost_render_path(sb_scene *s, const sb_render_params *p, int n, const double *poses6, uint32_t *frames) {
+    try {
+        HipRaytracer rt(p->width, p->height, p->fovy > 0 ? p->fovy : PI / 4);
+        rt.MaxRecursion = p->max_recursion;
+        rt.Device = s->device;
+        rt.Devices = s->devices;
+        rt.UseReferenceKdTree = s->use_kd != 0;
+        rt.Antialiasing = p->aa_mode == 1 ? AbstractRaycaster::AAMode::SSAA : AbstractRaycaster::AAMode::None;
+        std::vector<CameraPose> path((size_t)n);
+        for (int i = 0; i < n; i++) path[i] = {V3(poses6 + 6 * i), V3(poses6 + 6 * i + 3)};
+        const unsigned int *px = rt.RenderPathSync(s->scene.get(), path);
+        s->last_stats = rt.GetLastStats();
+        s->compiled = false;
+        s->uploaded = false;
+        if (!px) { g_host_err = "interrupted"; return RTHIP_E_INTERRUPTED; }
+        std::memcpy(frames, px, sizeof(uint32_t) * (size_t)n * p->width * p->height);
+        return 0;
+    } catch (const DeviceError &e) {
+        g_host_err = e.what();
+        return e.Code;
+    } catch (const std::exception &e) {
+        g_host_err = e.what();
+        return RTHIP_E_INVALID;
+    }
+}
+
 // Two frames through ONE renderer with Mesh::NormalMode of every mesh flipped (Face <-> Vertex) in between: a public field
 // the reference reads live per hit (Scene.cpp:456) and whose change does not invalidate the mesh.  Returns the second
 // frame and whether the geometry stayed on the device.  The scene keeps the flipped modes.
