@@ -194,32 +194,55 @@ RT_HD V3 xform(const double *m, V3 p, double w) {
 RT_HD double lerp(double a, double b, double t) { return a * (1 - t) + b * t; }              // Common.h:27-30
 RT_HD double fade(double t) { return t * t * t * (t * (t * 6 - 15) + 10); }                 // Perlin.cpp:59-62
 
-// Perlin.cpp:57-83 SampleAtFrequency + Perlin.cpp:49-55 GetSeed.  frequency is a power of two,
-// so the reference's divisions by it are exact scalings (x / 2^k == x * 2^-k bit for bit).
-// The 24 chained table lookups of the reference collapse to 14 distinct ones.
-RT_HD double perlin_at_freq(const uint8_t *tab, V3 pos, double fq, double inv_fq) {
-    double fx = floor(pos.x * inv_fq) * fq, fy = floor(pos.y * inv_fq) * fq, fz = floor(pos.z * inv_fq) * fq;
-    uint32_t x0 = (uint32_t)fx, y0 = (uint32_t)fy, z0 = (uint32_t)fz;
-    uint32_t x1 = (uint32_t)(fx + fq), y1 = (uint32_t)(fy + fq), z1 = (uint32_t)(fz + fq);
+// Perlin.cpp:57-83 SampleAtFrequency + Perlin.cpp:49-55 GetSeed.  frequency F is a power of two, so the reference's divisions by
+// it are exact scalings (x / 2^k == x * 2^-k bit for bit), and its cell corner floor(pos / F) * F is floor(pos) with the low bits
+// cleared: (ipx, ipy, ipz) = floor(pos) as integers (once per sample), min = ip & ~(F - 1), max = min + F - the same integers the
+// reference converts from doubles (pos >= 0 here: every caller wraps the point into the domain first, Noise.cpp:3-19).
+// The 24 chained table lookups of the reference collapse to 14 distinct ones.  (The 256-byte table spans the 64 LDS banks exactly
+// once, so byte lookups never conflict; the same table as 256 doubles - no conversion, no scaling: 16 instructions fewer per
+// octave - spans them eight times and was 1.5 - 4 % SLOWER per frame: conflicts cost more than the instructions saved.)
+struct PerlinCell {
+    uint32_t ipx, ipy, ipz;
+};
+RT_HD double perlin_corner(const uint8_t *tab, uint32_t idx) { return tab[idx & 255u] * (1.0 / 256.0); }
+RT_HD double perlin_trilinear(V3 pos, double fx, double fy, double fz, double inv_fq, double a, double b, double c, double d, double e,
+                              double f, double g, double h) {
+    double u = fade((pos.x - fx) * inv_fq), v = fade((pos.y - fy) * inv_fq), w = fade((pos.z - fz) * inv_fq);
+    return lerp(lerp(lerp(a, b, u), lerp(c, d, u), v), lerp(lerp(e, f, u), lerp(g, h, u), v), w);
+}
+RT_HD double perlin_at_freq(const uint8_t *tab, V3 pos, PerlinCell ip, uint32_t F, double inv_fq) {
+    const uint32_t mask = ~(F - 1u);
+    const uint32_t x0 = ip.ipx & mask, y0 = ip.ipy & mask, z0 = ip.ipz & mask;
+    const uint32_t x1 = x0 + F, y1 = y0 + F, z1 = z0 + F;
     uint32_t ix0 = tab[x0 & 255u], ix1 = tab[x1 & 255u];
     uint32_t i00 = tab[(ix0 + y0) & 255u], i10 = tab[(ix1 + y0) & 255u];
     uint32_t i01 = tab[(ix0 + y1) & 255u], i11 = tab[(ix1 + y1) & 255u];
-    const double k = 1.0 / 256.0;
-    double a = tab[(i00 + z0) & 255u] * k, b = tab[(i10 + z0) & 255u] * k;
-    double c = tab[(i01 + z0) & 255u] * k, d = tab[(i11 + z0) & 255u] * k;
-    double e = tab[(i00 + z1) & 255u] * k, f = tab[(i10 + z1) & 255u] * k;
-    double g = tab[(i01 + z1) & 255u] * k, h = tab[(i11 + z1) & 255u] * k;
-    double u = fade((pos.x - fx) * inv_fq), v = fade((pos.y - fy) * inv_fq), w = fade((pos.z - fz) * inv_fq);
-    return lerp(lerp(lerp(a, b, u), lerp(c, d, u), v), lerp(lerp(e, f, u), lerp(g, h, u), v), w);
+    double a = perlin_corner(tab, i00 + z0), b = perlin_corner(tab, i10 + z0);
+    double c = perlin_corner(tab, i01 + z0), d = perlin_corner(tab, i11 + z0);
+    double e = perlin_corner(tab, i00 + z1), f = perlin_corner(tab, i10 + z1);
+    double g = perlin_corner(tab, i01 + z1), h = perlin_corner(tab, i11 + z1);
+    return perlin_trilinear(pos, (double)x0, (double)y0, (double)z0, inv_fq, a, b, c, d, e, f, g, h);
 }
 // Perlin.cpp:25-47 SampleNormalized
 RT_HD double perlin_normalized(const uint8_t *tab, uint32_t octaves, double persistance, V3 p) {
     double amplitude = 1.0, acc = 0.0, result = 0.0;
-    double fq = 256.0, inv_fq = 1.0 / 256.0;
     V3 rpos = scale(p, 256.0);
-    for (uint32_t i = 0; i < octaves; i++) {
-        result += amplitude * perlin_at_freq(tab, rpos, fq, inv_fq);
-        fq *= 0.5;
+    PerlinCell ip;
+    ip.ipx = (uint32_t)floor(rpos.x); ip.ipy = (uint32_t)floor(rpos.y); ip.ipz = (uint32_t)floor(rpos.z);
+    {   // octave 0, frequency 256 = the table's period: the eight corners are the same table entry (every corner coordinate is
+        // a multiple of 256), so one chain of three lookups serves all of them; the interpolation still runs (a * (1 - t) + a * t
+        // rounds, it need not give a back)
+        const uint32_t x0 = ip.ipx & ~255u, y0 = ip.ipy & ~255u, z0 = ip.ipz & ~255u;
+        const double a = perlin_corner(tab, tab[tab[0]]);
+        result += amplitude * perlin_trilinear(rpos, (double)x0, (double)y0, (double)z0, 1.0 / 256.0, a, a, a, a, a, a, a, a);
+        acc += amplitude;
+        amplitude *= persistance;
+    }
+    uint32_t F = 128u;
+    double inv_fq = 1.0 / 128.0;
+    for (uint32_t i = 1; i < octaves; i++) {
+        result += amplitude * perlin_at_freq(tab, rpos, ip, F, inv_fq);
+        F >>= 1;
         inv_fq *= 2.0;
         acc += amplitude;
         amplitude *= persistance;

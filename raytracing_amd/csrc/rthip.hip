@@ -883,6 +883,7 @@ __device__ __forceinline__ void shade_stats_flush(const Work &w, ShadeShared &sh
         *slot = v;
     }
 }
+// The Perlin tables of the scene in LDS (their chained lookups are the latency chain of every sky / marble sample), 256 bytes each
 __device__ __forceinline__ void stage_perlin_tables(const SceneView &sv, uint32_t n_tables) {
     const uint32_t words = n_tables * 64;
     const uint32_t *src = reinterpret_cast<const uint32_t *>(sv.perlin_tables);
