@@ -47,11 +47,18 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s pe
 # non-fused x86-64 reference), so every fp64 instruction is ONE flop: the usable peak of this code is half, 39.3 TFLOP/s.
 FP64_VALU_PEAK_TFLOPS = 78.6
 FP64_VALU_PEAK_UNFUSED_TFLOPS = 39.3
-PMC_CFG3 = os.path.join("profiles", "r02_pmc_summary_config3_batch8.json")
-PMC_CFG4 = os.path.join("profiles", "r02_pmc_summary_config4.json")
-PMC_TRAFFIC = os.path.join("profiles", "r02_pmc_traffic.json")
-PMC_CFG5_HBM = os.path.join("profiles", "r03_pmc_config5_hbm.json")
+# the committed PMC summaries the measured side of the rooflines is quoted from (tracked files; tools/prof_round.sh makes them)
+def _newest(*names):
+    for n in names:
+        if os.path.exists(os.path.join(ROOT, "profiles", n)):
+            return os.path.join("profiles", n)
+    return os.path.join("profiles", names[0])
 
+
+PMC_CFG3 = _newest("r03_pmc_summary_config3_batch8.json", "r02_pmc_summary_config3_batch8.json")
+PMC_CFG4 = _newest("r03_pmc_summary_config4.json", "r02_pmc_summary_config4.json")
+PMC_CFG5 = _newest("r03_pmc_summary_config5.json")
+PMC_TRAFFIC = _newest("r03_pmc_traffic.json", "r02_pmc_traffic.json")
 
 # ALGORITHMIC flops of the dominant kernel (SURVEY.md §8d "ALGORITHMIC flops per ray": fixed weights x measured counts), for
 # k_trace_quad's units of work:
@@ -211,14 +218,14 @@ def measured_traffic():
     """HBM bytes per launch of the dominant kernel from the committed PMC passes (tools/prof_traffic.sh: separate rocprofv3
     --pmc runs of FETCH_SIZE and WRITE_SIZE over this very workload, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes
     for gfx950)."""
-    t = _load(PMC_TRAFFIC) or _load(os.path.join("profiles", "r01_pmc_traffic.json"))
+    t = _load(PMC_TRAFFIC)
     return None if t is None else t.get("k_trace_quad_bytes_per_launch")
 
 
-def measured_valu(rel=PMC_CFG3, fallback=os.path.join("profiles", "r01_pmc_summary_config3_batch8.json")):
+def measured_valu(rel=PMC_CFG3):
     """VALU issue utilisation / active lanes / waiting fraction of the dominant kernel from the committed PMC passes over the
     bench's own shape of work (`tools/prof_passes.sh <tag> 3 4 8` + prof_summary.py): the measured side of the VALU roof."""
-    src = rel if _load(rel) else fallback
+    src = rel
     j = _load(src)
     if j is None:
         return None
@@ -266,6 +273,20 @@ def cpu_baseline(sd, frames=5):
     return out
 
 
+def hbm_roofline(pmc_rel, kernel="k_trace_quad<false>"):
+    """HBM roof of a kernel from a committed PMC summary: bytes per frame (FETCH_SIZE x 2 + WRITE_SIZE, separate passes) over the
+    kernel's own time in the same passes"""
+    pmc = _load(pmc_rel)
+    k = pmc and pmc["kernels"].get(kernel)
+    if not (k and k.get("hbm_bytes_per_frame")):
+        return None
+    gbs = k["hbm_bytes_per_frame"] / (k["gpu_ms_per_frame_serialised"] * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": kernel.split("<")[0], "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+            "traffic": k["hbm_bytes_per_frame"], "kernel_ms_per_frame": k["gpu_ms_per_frame_serialised"],
+            "valu_issue_util": k.get("valu_issue_util"), "active_lanes_per_valu_inst": k.get("active_lanes_per_valu_inst"),
+            "l2_hit_rate": k.get("l2_hit_rate"), "source": pmc_rel}
+
+
 def config4_line(local_rank, frames=5):
     """BASELINE configs[3] on ONE GPU, lone frames left in HBM: the 2 097 152-triangle height field + 16 reflective spheres,
     3840x2160, MaxRecursion 4 - the workload whose BVH + triangles (0.6 GB) do not fit L2, i.e. where HBM is the roof.
@@ -298,14 +319,17 @@ def config4_line(local_rank, frames=5):
             ctx.render_device(cam, prm, fb.data_ptr(), sync=True)
         st = ctx.stats()
         rays = st.rays_primary + st.rays_shadow + st.rays_reflect
-        ts = []
+        ts, wall = [], []
         for _ in range(frames):
             t = time.perf_counter()
             ctx.render_device(cam, prm, fb.data_ptr(), sync=True)
-            ts.append((time.perf_counter() - t) * 1e3)
+            wall.append((time.perf_counter() - t) * 1e3)   # the synchronous call: + the statistics read-back
+            ts.append(float(ctx.stats().ms_total))          # the frame on the device (HIP events around its launches)
         ts.sort()
+        wall.sort()
         ms = ts[len(ts) // 2]
-        runs[name] = {"rays_per_frame": int(rays), "ms_per_frame": ms, "value": rays / ms / 1e3, "frame_checksum": int(fb.to(torch.int64).sum().item()),
+        runs[name] = {"rays_per_frame": int(rays), "ms_per_frame": ms, "ms_per_synchronous_call": wall[len(wall) // 2], "value": rays / ms / 1e3,
+                      "frame_checksum": int(fb.to(torch.int64).sum().item()),
                       "scene_construction_s": t0 - tc, "scene_compile_flatten_s": t1 - t0, "scene_upload_and_device_build_s": t2 - t1,
                       "kd_tree": {"built_on": "device" if up.kd_meshes else "host", "device_ms": up.kd_device_ms, "nodes": int(up.kd_nodes) or None,
                                   "leaf_refs": int(up.kd_refs) or None, "levels": int(up.kd_levels) or None},
@@ -322,15 +346,9 @@ def config4_line(local_rank, frames=5):
            "rays_per_frame": best["rays_per_frame"], "ms_per_frame": best["ms_per_frame"], "value": best["value"], "unit": "Mrays/s", "frames": frames,
            "frame_checksum": best["frame_checksum"], "frames_identical": runs["trees_built_on_host"]["frame_checksum"] == best["frame_checksum"],
            "trees_built_on_host": runs["trees_built_on_host"], "trees_built_on_device": runs["trees_built_on_device"]}
-    pmc = _load(PMC_CFG4) or _load(os.path.join("profiles", "r01_pmc_summary_config4.json"))
-    k = pmc and pmc["kernels"].get("k_trace_quad<false>")
-    if k and k.get("hbm_bytes_per_frame"):
-        # HBM roof of the dominant kernel on THIS config: PMC bytes per frame (FETCH_SIZE x 2 + WRITE_SIZE, separate passes)
-        # over the kernel's own time in the same passes
-        gbs = k["hbm_bytes_per_frame"] / (k["gpu_ms_per_frame_serialised"] * 1e-3) / 1e9
-        out["roofline"] = {"bound": "hbm", "kernel": "k_trace_quad", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                           "traffic": k["hbm_bytes_per_frame"], "kernel_ms_per_frame": k["gpu_ms_per_frame_serialised"],
-                           "valu_issue_util": k.get("valu_issue_util"), "l2_hit_rate": k.get("l2_hit_rate"), "source": pmc.get("source_file")}
+    rf = hbm_roofline(PMC_CFG4)
+    if rf:
+        out["roofline"] = rf
     return out
 
 
@@ -458,13 +476,16 @@ def main():
     cctx.render_batch_device(cam_run(0, B), prm, scratch.data_ptr(), sync=True)
     cst = cctx.stats()
     aflops = algorithmic_flops(cst)  # per call (the first B cameras of the path)
-    path_rays = []                   # this rank's rays of every camera of the path
+    cctx.close()
+    rctx = device.Context(local_rank)  # (ray counts are always collected: a plain context)
+    rctx.upload(desc)
+    path_rays = []                     # this rank's rays of every camera of the path
     for f in range(PATH):
-        cctx.render_batch_device(cam_run(f, 1), prm, scratch.data_ptr(), sync=True)
-        st1 = cctx.stats()
+        rctx.render_batch_device(cam_run(f, 1), prm, scratch.data_ptr(), sync=True)
+        st1 = rctx.stats()
         path_rays.append(int(st1.rays_primary + st1.rays_shadow + st1.rays_reflect))
     my_rays_timed = sum(path_rays[f % PATH] for f in range(args.steps))  # exactly the frames of one timed burst
-    cctx.close()
+    rctx.close()
     del scratch
 
     # Timed contexts: `inflight` frames are in flight at once, each on its own context (own HIP stream, own
@@ -614,7 +635,7 @@ def main():
         if not args.no_config5:
             others["config5"] = config_object("BASELINE configs[4] on ONE GPU: five rotated / scaled 2 097 152-triangle height fields (10 485 760 triangles) + 16 "
                                               "reflective spheres + checker plane + SkyBox, 7680x4320, MaxRecursion 8, lone frames (two workspace chunks)",
-                                              *scenes.config(5), local_rank, frames=3, hbm_pmc=_load(PMC_CFG5_HBM))
+                                              *scenes.config(5), local_rank, frames=3, hbm_pmc=hbm_roofline(PMC_CFG5))
     red_dev = "cpu" if args.rehearse_on_one_gpu else "cuda"
     rays_t = torch.tensor([float(my_rays_timed), float(path_rays[0])], dtype=torch.float64, device=red_dev)
     dt_t = torch.tensor(samples, dtype=torch.float64, device=red_dev)

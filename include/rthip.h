@@ -240,14 +240,16 @@ typedef struct {
                                                         * mesh-walk kernel k_trace_quad (accel = 0) or k_trace (accel = 1) */
     uint32_t launches_trace;                           /* number of launches of that kernel (= recursion levels traced) */
     uint32_t pad;
-    /* only collected by contexts created with RTHIP_COUNTERS=1 in the environment: */
-    uint64_t kd_nodes_visited;   /* kd node records fetched (16 B each) */
-    uint64_t kd_tris_tested;     /* triangle records tested (128 B + 4 B reference each) */
-    uint64_t kd_leaves_visited;
-    uint64_t kd_pops;            /* pending subtrees resumed (48 B of bounds each) */
+    /* only collected by contexts created with RTHIP_COUNTERS=1 in the environment.  The traversal counters count the structure
+     * the frame WALKED: with accel = 1 the reference kd-tree (the names they were given in round 1), with accel = 0 - the
+     * default - the 4-wide BVH; each has an alias that says so (same storage): */
+    union { uint64_t kd_nodes_visited;  uint64_t bvh_steps; };          /* kd node records fetched (16 B each) / BVH node steps (one 128-byte node = 4 child boxes) */
+    union { uint64_t kd_tris_tested;    uint64_t tris_tested; };        /* triangle records tested (128 B + 4 B reference each) */
+    union { uint64_t kd_leaves_visited; uint64_t bvh_leaf_steps; };     /* leaves visited (BVH: leaf steps of <= 4 triangles) */
+    union { uint64_t kd_pops;           uint64_t bvh_culled_pops; };    /* kd: pending subtrees resumed (48 B of bounds each) / BVH: stack entries popped already culled */
     uint64_t shape_tests;        /* shape-table entries tested (world->local transform fetch) */
     uint64_t mesh_hits;          /* mesh hits whose vertex normals were fetched (72 B) */
-    uint64_t kd_max_nodes_ray;   /* most node records any single ray (all its queries) fetched (tail-latency diagnostic) */
+    union { uint64_t kd_max_nodes_ray; uint64_t max_steps_ray; };       /* most node records / steps any single ray (all its queries) took (tail-latency diagnostic) */
     /* divergence diagnostics: BVH interior steps / triangle-test iterations executed per WAVE (a wave
      * executes a step when any of its lanes does): the largest of any wave over the frame (summed over
      * the grid-stride iterations of that wave), and the totals */

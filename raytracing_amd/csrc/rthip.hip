@@ -811,8 +811,6 @@ __device__ __forceinline__ void shade_and_spawn(const SceneView &sv, const Frame
     so.spawn = false;
     so.shadow_rays = 0;
     if (have) {
-        if (fp.count_kd == 1)  // counting context: what was shaded, for the flop accounting of this kernel (bench.py)
-            atomicAdd(&w.stats[ST_COUNT + (HARD ? 0u : kShadeCounts) + (h.shape < 0 ? kShadeCountShapes : min((uint32_t)h.shape, kShadeCountShapes - 1u))], 1ull);
         if (fp.renderer == RTHIP_RENDER_RAYTRACER) {
             shade_stage(sv, tabs, h, d, level < fp.max_rec, so);
         } else {
@@ -822,6 +820,18 @@ __device__ __forceinline__ void shade_and_spawn(const SceneView &sv, const Frame
         ColRec cr;
         cr.r = so.color.r; cr.g = so.color.g; cr.b = so.color.b; cr.refl = so.refl;
         rec_at(w, level, i) = cr;
+    }
+    if (fp.count_kd == 1) {  // counting context: what was shaded, for the flop accounting of this kernel (bench.py); one atomic per
+                             // wave and distinct shape (a 4K frame of sky sent millions of atomics to one address otherwise)
+        const uint32_t key = h.shape < 0 ? kShadeCountShapes : min((uint32_t)h.shape, kShadeCountShapes - 1u);
+        unsigned long long todo = __ballot(have);
+        while (todo) {
+            const int leader = __ffsll((long long)todo) - 1;
+            const uint32_t k = (uint32_t)__shfl((int)key, leader, 64);
+            const unsigned long long same = __ballot(have && key == k);
+            if ((int)lane == leader) atomicAdd(&w.stats[ST_COUNT + (HARD ? 0u : kShadeCounts) + k], (unsigned long long)__popcll(same));
+            todo &= ~same;
+        }
     }
     const unsigned long long mask = __ballot(so.spawn);
     const unsigned long long hmask = HARD ? __ballot(is_hard) : 0ull;

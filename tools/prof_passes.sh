@@ -5,7 +5,7 @@ export TMPDIR=/tmp
 tag=$1; cfg=$2; frames=$3; batch=${4:-1}
 out=gpurun_out/$tag
 mkdir -p $out
-pass() { name=$1; shift; timeout -s KILL 90 rocprofv3 --pmc "$@" --output-format csv -d $out/$name -- python3 tools/prof_frame.py $cfg $frames $batch > $out/$name.log 2>&1 || { echo "pass $name failed"; tail -3 $out/$name.log; exit 1; }; }
+pass() { name=$1; shift; timeout -s KILL ${PASS_TIMEOUT:-90} rocprofv3 --pmc "$@" --output-format csv -d $out/$name -- python3 tools/prof_frame.py $cfg $frames $batch > $out/$name.log 2>&1 || { echo "pass $name failed"; tail -3 $out/$name.log; exit 1; }; }
 pass sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_LEVEL_WAVES
 pass sq2 SQ_IFETCH SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_THREAD_CYCLES_VALU SQ_INSTS_VALU_TRANS_F64
 pass sqc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_DCACHE_REQ SQC_DCACHE_MISSES

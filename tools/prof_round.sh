@@ -6,7 +6,7 @@
 # usage: bash tools/prof_round.sh <tag>      -> gpurun_out/<tag>_*
 set -u
 export TMPDIR=/tmp
-tag=${1:-r02}
+tag=${1:-r03}
 o=gpurun_out
 timeout -k 10 300 python3 bench.py > $o/${tag}_bench.json 2> $o/${tag}_bench.err || { echo "bench failed"; tail -5 $o/${tag}_bench.err; exit 1; }
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $o/${tag}_stats -- python3 bench.py --no-extras --no-cpu-baseline > $o/${tag}_stats.json 2> $o/${tag}_stats.err || { echo "stats run failed"; tail -5 $o/${tag}_stats.err; exit 1; }
@@ -16,4 +16,9 @@ python3 tools/prof_summary.py $o/${tag}_pmc_cfg3_b8 32 $o/${tag}_pmc_summary_con
 bash tools/prof_passes.sh ${tag}_pmc_cfg4 4 3 > $o/${tag}_pmc_cfg4.txt 2>&1 || { echo "pmc cfg4 failed"; tail -5 $o/${tag}_pmc_cfg4.txt; exit 1; }
 python3 tools/prof_summary.py $o/${tag}_pmc_cfg4 3 $o/${tag}_pmc_summary_config4.json > $o/${tag}_pmc_summary_config4.md
 bash tools/prof_traffic.sh ${tag}_traffic > $o/${tag}_traffic.txt 2>&1 || { echo "traffic failed"; tail -5 $o/${tag}_traffic.txt; exit 1; }
+# config 5 (10.5 M triangles, 8K, one frame per pass: ~40 s of scene construction each)
+if [ "${PROF_CFG5:-1}" = "1" ]; then
+  bash tools/prof_passes.sh ${tag}_pmc_cfg5 5 1 > $o/${tag}_pmc_cfg5.txt 2>&1 || { echo "pmc cfg5 failed"; tail -5 $o/${tag}_pmc_cfg5.txt; exit 1; }
+  python3 tools/prof_summary.py $o/${tag}_pmc_cfg5 1 $o/${tag}_pmc_summary_config5.json > $o/${tag}_pmc_summary_config5.md
+fi
 echo "round profile done"

@@ -38,6 +38,8 @@ for k, c in sorted(acc.items()):
                   "hbm_bytes_per_frame": hbm, "hbm_fetch_bytes_per_frame": c.get("FETCH_SIZE", 0) * 2 * 1024 / frames,
                   "hbm_write_bytes_per_frame": c.get("WRITE_SIZE", 0) * 1024 / frames}
 if len(sys.argv) > 3:  # machine-readable copy (bench.py quotes the dominant kernel's VALU figures from it)
-    json.dump({"source": d, "source_file": sys.argv[3], "frames": frames, "kernels": summary}, open(sys.argv[3], "w"), indent=1)
+    import os
+    json.dump({"source": "rocprofv3 --pmc passes of tools/prof_passes.sh (" + os.path.basename(d.rstrip("/")) + "), summarised by tools/prof_summary.py",
+               "source_file": "profiles/" + os.path.basename(sys.argv[3]), "frames": frames, "kernels": summary}, open(sys.argv[3], "w"), indent=1)
 print("\nVALU issue utilisation = 4 cycles x SQ_ACTIVE_INST_VALU / (1024 SIMDs x kernel cycles); HBM/MALL read = TCC_EA0_RDREQ x 128 B "
       "(gfx950 tallies 128-byte requests, MI355X_MICROARCH.md); GPU ms from GRBM_GUI_ACTIVE at 2.4 GHz (PMC runs serialise kernels).")
