@@ -1386,6 +1386,32 @@ RT_HD Col debug_raycast(const SceneView &sv, V3 o, V3 d, int mode, KdStack &st, 
 // ----------------------------------------------------------------------------- ray generation (R1)
 // AbstractRaycaster::CreateScreenRay (Raytracer.cpp:102-121) with the camera basis, h2 and w2
 // hoisted to the host (rthip_camera); x, y are the real pixel coordinates (integers, or +-0.5 for SSAA).
+// Division of a 32-bit index by a divisor that is the same for a whole launch (tile sizes, slots per chunk): the GPU has no integer
+// divide, `n / d` is ~25 instructions and the slot -> pixel mapping of every level-0 ray holds five of them.  Granlund & Montgomery
+// 1994, figure 4.1 with N = 32: for l = ceil(log2 d), m' = floor(2^32 (2^l - d) / d) + 1, every 0 <= n < 2^32 has
+// floor(n / d) = (t + ((n - t) >> min(l, 1))) >> max(l - 1, 0) with t = the high word of m' * n.  The host computes (m', shifts) once.
+struct FastDiv {
+    uint32_t m;
+    uint32_t s;  // min(l, 1) | max(l - 1, 0) << 8
+};
+inline FastDiv make_fastdiv(uint32_t d) {
+    FastDiv f;
+    if (d == 0) d = 1;
+    uint32_t l = 0;
+    while (l < 32 && ((uint64_t)1 << l) < d) l++;
+    f.m = (uint32_t)((((uint64_t)1 << 32) * (((uint64_t)1 << l) - d)) / d + 1);
+    f.s = (l ? 1u : 0u) | ((l ? l - 1u : 0u) << 8);
+    return f;
+}
+RT_HD uint32_t fast_div(uint32_t n, FastDiv f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t t = __umulhi(f.m, n);
+#else
+    const uint32_t t = (uint32_t)(((uint64_t)f.m * n) >> 32);
+#endif
+    return (t + ((n - t) >> (f.s & 255u))) >> (f.s >> 8);
+}
+
 RT_HD void screen_ray(const rthip_camera &cam, uint32_t W, uint32_t H, double x, double y, V3 &o, V3 &d) {
     double xFactor = (x / (double)W) * 2.0 - 1.0;
     double yFactor = 1.0 - (y / (double)H) * 2.0;

@@ -126,6 +126,7 @@ struct FrameParams {
     uint32_t N0;           // level-0 rays of this chunk = n_pix_slots * (aa ? 9 : 1)
     uint32_t count_kd;     // collect kd counters
     int32_t layout;        // 0 frame, 1 tile-compact
+    rtc::FastDiv d_per_tile, d_my_tiles, d_tiles_x, d_sbx, d_pix_slots;  // divisions of slot_to_pixel / primary_ray (see rtc::fast_div)
 };
 // Per-frame device workspace.  Every per-ray record is ONE aligned array-of-structs entry (a 64-byte
 // ray, a 64-byte hit, a 32-byte colour): a lane reads or writes whole cache lines with dwordx4
@@ -232,21 +233,25 @@ __device__ __forceinline__ void store_no_ray(const Work &w, uint32_t i) {
 // as 8x8 sub-blocks, and inside a sub-block as four 4x4 patches: 16 consecutive slots (the rays of one
 // wave of the quad trace kernel) cover a compact 4x4 patch, 64 (one shade wave) an 8x8 one.
 // `frame` = index within the batch, `part_slot` = slot within that frame's part (tile-compact order).
+// ONE_FRAME: the caller's slots all lie in frame 0 (k_assemble: one part buffer of one frame)
+template <bool ONE_FRAME = false>
 __device__ __forceinline__ bool slot_to_pixel(const FrameParams &fp, uint32_t pix_slot, uint32_t &x, uint32_t &y, uint32_t &frame,
                                               uint32_t &part_slot) {
-    uint32_t per_tile = fp.tile_w * fp.tile_h;
-    uint32_t q = fp.q0 + pix_slot / per_tile;
-    uint32_t r = pix_slot % per_tile;
-    frame = q / fp.my_tiles;
+    const uint32_t per_tile = fp.tile_w * fp.tile_h;
+    const uint32_t qc = rtc::fast_div(pix_slot, fp.d_per_tile);
+    uint32_t q = fp.q0 + qc;
+    const uint32_t r = pix_slot - qc * per_tile;
+    frame = ONE_FRAME ? 0u : rtc::fast_div(q, fp.d_my_tiles);
     q -= frame * fp.my_tiles;
     part_slot = q * per_tile + r;
-    uint32_t t = fp.part_index + q * fp.part_count;
+    const uint32_t t = fp.part_index + q * fp.part_count;
     if (t >= fp.tiles_x * fp.tiles_y || frame >= fp.n_frames) return false;
-    uint32_t tx = t % fp.tiles_x, ty = t / fp.tiles_x;
-    uint32_t sb = r >> 6, l = r & 63u;
-    uint32_t sbx = fp.tile_w >> 3;
-    x = tx * fp.tile_w + (sb % sbx) * 8 + ((l & 3u) | ((l >> 2) & 4u));
-    y = ty * fp.tile_h + (sb / sbx) * 8 + (((l >> 2) & 3u) | ((l >> 3) & 4u));
+    const uint32_t ty = rtc::fast_div(t, fp.d_tiles_x), tx = t - ty * fp.tiles_x;
+    const uint32_t sb = r >> 6, l = r & 63u;
+    const uint32_t sbx = fp.tile_w >> 3;
+    const uint32_t sby = rtc::fast_div(sb, fp.d_sbx);
+    x = tx * fp.tile_w + (sb - sby * sbx) * 8 + ((l & 3u) | ((l >> 2) & 4u));
+    y = ty * fp.tile_h + sby * 8 + (((l >> 2) & 3u) | ((l >> 3) & 4u));
     return x < fp.W && y < fp.H;
 }
 
@@ -254,7 +259,7 @@ __device__ __forceinline__ bool slot_to_pixel(const FrameParams &fp, uint32_t pi
 // False when the slot lies outside the image.  The 64 slots of a wave lie in one tile, hence in one frame of the
 // batch: the camera is read with scalar loads (lane 0 is live whenever any lane of the wave is).
 __device__ __forceinline__ bool primary_ray(const FrameParams &fp, uint32_t i, bool live, uint32_t &pix_slot, V3 &o, V3 &d) {
-    uint32_t s = i / fp.n_pix_slots;  // SSAA sub-sample (0 when aa is off)
+    uint32_t s = fp.aa ? rtc::fast_div(i, fp.d_pix_slots) : 0u;  // SSAA sub-sample (without SSAA the chunk holds one ray per slot)
     pix_slot = i - s * fp.n_pix_slots;
     uint32_t x = 0, y = 0, frame = 0, part_slot = 0;
     const bool inside = slot_to_pixel(fp, pix_slot, x, y, frame, part_slot);
@@ -355,7 +360,7 @@ __global__ __launch_bounds__(kBlock, RT_TRACE_OCC) void k_trace(SceneView sv, Fr
         V3 o = mk(0, 0, 0), d = mk(0, 0, 1);
         uint32_t pix_slot = 0;
         bool live = in_range;
-        if (level == 0) pix_slot = i % fp.n_pix_slots;
+        if (level == 0) pix_slot = fp.aa ? i - rtc::fast_div(i, fp.d_pix_slots) * fp.n_pix_slots : i;
         if (level == 0 && !REDO) {
             if (!primary_ray(fp, i, live, pix_slot, o, d)) {
                 if (live) store_no_ray(w, i);  // slot outside the image
@@ -1122,7 +1127,7 @@ __global__ __launch_bounds__(kBlock, RT_QUAD_OCC) void k_trace_quad(SceneView sv
         const uint32_t i = live ? w.hard[j] : 0u;
         const uint32_t nodes_before = kc.nodes;
         uint32_t pix_slot = 0;
-        if (level == 0) pix_slot = i % fp.n_pix_slots;
+        if (level == 0) pix_slot = fp.aa ? i - rtc::fast_div(i, fp.d_pix_slots) * fp.n_pix_slots : i;
         {   // level 0 too: k_trace_easy has stored the primary rays it listed
             V3 o = mk(0, 0, 0), d = mk(0, 0, 1);
             if (live) {
@@ -1364,7 +1369,7 @@ __global__ __launch_bounds__(kBlock) void k_assemble(FrameParams fp, const uint3
     if (part >= n_tiles) return;
     fp.my_tiles = (n_tiles - part + fp.part_count - 1) / fp.part_count;
     uint32_t x, y, f0, slot;
-    if (!slot_to_pixel(fp, ps, x, y, f0, slot)) return;
+    if (!slot_to_pixel<true>(fp, ps, x, y, f0, slot)) return;
     frame[((size_t)b * fp.H + y) * fp.W + x] = gathered[((size_t)part * gridDim.z + b) * part_slots + ps];
 }
 
@@ -2103,6 +2108,10 @@ static int render_frame(rthip_ctx *c, const rthip_camera *cam, uint32_t n_frames
     const uint32_t n_tiles = fp.tiles_x * fp.tiles_y;
     const uint32_t frame_tiles = n_tiles > fp.part_index ? (n_tiles - fp.part_index + fp.part_count - 1) / fp.part_count : 0;
     fp.my_tiles = frame_tiles ? frame_tiles : 1;
+    fp.d_per_tile = rtc::make_fastdiv(fp.tile_w * fp.tile_h);
+    fp.d_my_tiles = rtc::make_fastdiv(fp.my_tiles);
+    fp.d_tiles_x = rtc::make_fastdiv(fp.tiles_x);
+    fp.d_sbx = rtc::make_fastdiv(fp.tile_w >> 3);
     const uint32_t my_tiles = frame_tiles * n_frames;  // tile ordinals of the whole batch
     const uint32_t per_tile = fp.tile_w * fp.tile_h;
     const uint32_t spp = fp.aa ? 9 : 1;
@@ -2266,6 +2275,7 @@ static int render_frame(rthip_ctx *c, const rthip_camera *cam, uint32_t n_frames
         uint32_t nq = my_tiles - q0 < tiles_per_chunk ? my_tiles - q0 : tiles_per_chunk;
         fp.q0 = q0;
         fp.n_pix_slots = nq * per_tile;
+        fp.d_pix_slots = rtc::make_fastdiv(fp.n_pix_slots);
         fp.N0 = fp.n_pix_slots * spp;
         w.stage_base = (q0 / tiles_per_chunk) * stages_per_chunk + 1;  // (stage 0 = nothing begun yet)
         if (q0)  // (the first chunk's were cleared with the statistics)
@@ -2602,6 +2612,10 @@ int rthip_assemble_batch(rthip_ctx *c, const rthip_params *p, uint32_t n_frames,
     fp.tile_h = p->tile_h ? p->tile_h : 8;
     fp.tiles_x = (fp.W + fp.tile_w - 1) / fp.tile_w;
     fp.tiles_y = (fp.H + fp.tile_h - 1) / fp.tile_h;
+    fp.d_per_tile = rtc::make_fastdiv(fp.tile_w * fp.tile_h);
+    fp.d_my_tiles = rtc::make_fastdiv(1);  // (k_assemble: one frame per part buffer, the division is skipped)
+    fp.d_tiles_x = rtc::make_fastdiv(fp.tiles_x);
+    fp.d_sbx = rtc::make_fastdiv(fp.tile_w >> 3);
     uint32_t part_slots = (uint32_t)rthip_part_pixels(p);
     hipLaunchKernelGGL(k_assemble, dim3((part_slots + kBlock - 1) / kBlock, p->part_count, n_frames), dim3(kBlock), 0, c->stream, fp,
                        (const uint32_t *)d_gathered, part_slots, (uint32_t *)d_frame);

@@ -31,6 +31,15 @@ static SceneView view_of(const rthip_scene_desc *s) {
 }
 
 extern "C" {
+// rtc::fast_div (the slot -> pixel mapping's divisions) against the hardware division: mismatches over n = lo, lo + step, ... < hi
+uint64_t hc_fastdiv_mismatches(uint32_t d, uint64_t lo, uint64_t hi, uint64_t step) {
+    const rtc::FastDiv f = rtc::make_fastdiv(d);
+    uint64_t bad = 0;
+    for (uint64_t n = lo; n < hi && n <= 0xffffffffull; n += step ? step : 1)
+        bad += rtc::fast_div((uint32_t)n, f) != (uint32_t)n / d;
+    return bad;
+}
+
 
 // frame with the same per-pixel semantics as k_bounce/k_fold/k_resolve
 int hc_render(const rthip_scene_desc *scene, const rthip_camera *cam, const rthip_params *p, uint32_t *pixels,

@@ -207,3 +207,26 @@ def test_threaded_scene_build_gives_the_single_threaded_arrays(host_lib, monkeyp
     for threads in ("8", "3"):
         for k, v in out["1"].items():
             assert out[threads][k] == v, f"{k} differs with {threads} build threads"
+
+
+def test_fast_division_of_the_slot_mapping_is_exact():
+    """rtc::fast_div (Granlund-Montgomery round-up multiplier, rt_core.hpp) replaces the integer divisions of slot_to_pixel /
+    primary_ray on the device; it must be floor(n / d) for EVERY 32-bit n: all n for small divisors, a dense sweep plus the ends of
+    the range for the divisors frames really use (tiles per row, slots per tile, tiles per part, slots per chunk) and for awkward
+    ones (2^k, 2^k +- 1, 0xffffffff)."""
+    import ctypes as C
+    lib = C.CDLL(os.path.join(os.path.dirname(__file__), "hostcore", "libhostcore.so"))
+    f = lib.hc_fastdiv_mismatches
+    f.restype = C.c_uint64
+    f.argtypes = [C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint64]
+    for d in list(range(1, 70)) + [120, 240, 255, 256, 257, 1000, 4096, 8100, 65535, 65536, 65537]:
+        assert f(d, 0, 1 << 22, 1) == 0, d
+    rng = np.random.default_rng(5)
+    ds = [1, 2, 3, 4, 60, 240, 256, 2073600, 16777216, 16777215, 16777217, 33177600, 0x7fffffff, 0x80000000, 0x80000001, 0xfffffffe, 0xffffffff]
+    ds += [int(x) for x in rng.integers(1, 1 << 32, 40)] + [int(x) for x in rng.integers(1, 1 << 16, 40)]
+    for d in ds:
+        assert f(d, 0, 1 << 32, 4099) == 0, d                      # a sweep of the whole range
+        assert f(d, (1 << 32) - (1 << 16), 1 << 32, 1) == 0, d      # the top of the range
+        for k in (1, 2, 3, 1000, (0xffffffff // d)):               # around multiples of d
+            lo = max(0, k * d - 70)
+            assert f(d, lo, min(1 << 32, k * d + 70), 1) == 0, (d, k)
