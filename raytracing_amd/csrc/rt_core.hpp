@@ -204,11 +204,14 @@ RT_HD double fade(double t) { return t * t * t * (t * (t * 6 - 15) + 10); }     
 struct PerlinCell {
     uint32_t ipx, ipy, ipz;
 };
-RT_HD double perlin_corner(const uint8_t *tab, uint32_t idx) { return tab[idx & 255u] * (1.0 / 256.0); }
+// The corner values are the table bytes / 256 (Perlin.cpp:49-55).  The interpolation is linear in them and a scaling by 2^-8 is
+// exact and commutes with every rounding (no result here comes near the subnormals), so the eight scalings are done once, on
+// the interpolated value: the corners go in as the integers 0..255 and the result is bit for bit the reference's.
+RT_HD double perlin_corner(const uint8_t *tab, uint32_t idx) { return (double)tab[idx & 255u]; }
 RT_HD double perlin_trilinear(V3 pos, double fx, double fy, double fz, double inv_fq, double a, double b, double c, double d, double e,
                               double f, double g, double h) {
     double u = fade((pos.x - fx) * inv_fq), v = fade((pos.y - fy) * inv_fq), w = fade((pos.z - fz) * inv_fq);
-    return lerp(lerp(lerp(a, b, u), lerp(c, d, u), v), lerp(lerp(e, f, u), lerp(g, h, u), v), w);
+    return lerp(lerp(lerp(a, b, u), lerp(c, d, u), v), lerp(lerp(e, f, u), lerp(g, h, u), v), w) * (1.0 / 256.0);
 }
 RT_HD double perlin_at_freq(const uint8_t *tab, V3 pos, PerlinCell ip, uint32_t F, double inv_fq) {
     const uint32_t mask = ~(F - 1u);
@@ -269,9 +272,25 @@ RT_HD double worley_normalized(const double *pts, int div, double step, V3 p) {
             }
     return distance / maxDistance * 10.0;
 }
+// fmodf(x, d), which is exact by definition, without the library's general algorithm (~50 instructions on the device) when d is a
+// power of two - the domains scenes use (1, 2, 4, 16): x * (1 / d) is then exact, k = trunc(x / d) an integer below 2^23, d * k exact,
+// and x - d * k is a multiple of ulp(x) below d, hence representable; the sign of the result is x's, as fmodf's (a zero included).
+RT_HD float fmodf_exact(float x, float d) {
+    uint32_t db;
+    __builtin_memcpy(&db, &d, 4);
+    const uint32_t e = (db >> 23) & 255u;
+    if ((db & 0x807fffffu) == 0u && e >= 64u && e <= 190u) {  // d = 2^(e - 127)
+        const uint32_t ib = (254u - e) << 23;
+        float inv;
+        __builtin_memcpy(&inv, &ib, 4);
+        const float t = x * inv;
+        if (fabsf(t) < 8388608.0f) return copysignf(fabsf(x - d * truncf(t)), x);  // (false for inf / NaN too)
+    }
+    return fmodf(x, d);
+}
 // Noise.cpp:3-19: fmodf rounds point and domain to float; its float result is divided by the double domain
 RT_HD double noise_wrap(double x, double domain) {
-    x = (double)fmodf((float)x, (float)domain) / domain;
+    x = (double)fmodf_exact((float)x, (float)domain) / domain;
     return x < 0 ? 1.0 + x : x;
 }
 RT_HD double noise_sample(const SceneView &sv, const uint8_t *tabs, int32_t ni, V3 p) {

@@ -31,6 +31,22 @@ static SceneView view_of(const rthip_scene_desc *s) {
 }
 
 extern "C" {
+// rtc::fmodf_exact against the C library's fmodf, bit for bit, over n float patterns starting at bits `lo` with stride `step`
+uint64_t hc_fmodf_mismatches(float d, uint64_t lo, uint64_t n, uint64_t step) {
+    uint64_t bad = 0;
+    for (uint64_t k = 0; k < n; k++) {
+        const uint32_t b = (uint32_t)(lo + k * step);
+        float x;
+        memcpy(&x, &b, 4);
+        const float a = rtc::fmodf_exact(x, d), r = fmodf(x, d);
+        uint32_t ab, rb;
+        memcpy(&ab, &a, 4);
+        memcpy(&rb, &r, 4);
+        bad += (ab != rb) && !(a != a && r != r);
+    }
+    return bad;
+}
+
 // rtc::fast_div (the slot -> pixel mapping's divisions) against the hardware division: mismatches over n = lo, lo + step, ... < hi
 uint64_t hc_fastdiv_mismatches(uint32_t d, uint64_t lo, uint64_t hi, uint64_t step) {
     const rtc::FastDiv f = rtc::make_fastdiv(d);

@@ -230,3 +230,20 @@ def test_fast_division_of_the_slot_mapping_is_exact():
         for k in (1, 2, 3, 1000, (0xffffffff // d)):               # around multiples of d
             lo = max(0, k * d - 70)
             assert f(d, lo, min(1 << 32, k * d + 70), 1) == 0, (d, k)
+
+
+def test_power_of_two_fmodf_is_the_library_fmodf_bit_for_bit():
+    """rtc::fmodf_exact (Noise::Sample's wrap, Noise.cpp:3-19, without the general fmodf on the device): every float pattern in a
+    stride sweep over the whole 32-bit space (both signs, zeros, subnormals, infinities, NaNs) and dense runs around the interesting
+    magnitudes, for power-of-two domains and for domains that take the library path"""
+    import ctypes as C
+    lib = C.CDLL(os.path.join(os.path.dirname(__file__), "hostcore", "libhostcore.so"))
+    f = lib.hc_fmodf_mismatches
+    f.restype = C.c_uint64
+    f.argtypes = [C.c_float, C.c_uint64, C.c_uint64, C.c_uint64]
+    for d in (1.0, 2.0, 4.0, 16.0, 0.5, 2.0 ** -20, 2.0 ** 20, 2.0 ** 63, 2.0 ** -63, 2.0 ** 64, 1.5, 3.0, -2.0, 1e-40):
+        assert f(d, 0, (1 << 32) // 1021 + 1, 1021) == 0, d                 # the whole space, every 1021st pattern
+        for centre in (0x00000000, 0x80000000, 0x3f800000, 0xbf800000, 0x4b000000, 0xcb000000, 0x7f800000, 0x00800000):
+            assert f(d, max(0, centre - 40000), 80000, 1) == 0, (d, hex(centre))
+        db = int(np.float32(d).view(np.uint32))
+        assert f(d, max(0, db - 40000), 80000, 1) == 0 and f(d, max(0, (db | 0x80000000) - 40000), 80000, 1) == 0, d
