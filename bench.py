@@ -55,10 +55,9 @@ def _newest(*names):
     return os.path.join("profiles", names[0])
 
 
-PMC_CFG3 = _newest("r03_pmc_summary_config3_batch8.json", "r02_pmc_summary_config3_batch8.json")
+PMC_CFG3 = _newest("r03_pmc_summary_config3_batch32.json", "r03_pmc_summary_config3_batch8.json", "r02_pmc_summary_config3_batch8.json")
 PMC_CFG4 = _newest("r03_pmc_summary_config4.json", "r02_pmc_summary_config4.json")
 PMC_CFG5 = _newest("r03_pmc_summary_config5.json")
-PMC_TRAFFIC = _newest("r03_pmc_traffic.json", "r02_pmc_traffic.json")
 
 # ALGORITHMIC flops of the dominant kernel (SURVEY.md §8d "ALGORITHMIC flops per ray": fixed weights x measured counts), for
 # k_trace_quad's units of work:
@@ -214,12 +213,15 @@ def _load(rel):
     return json.load(open(path)) if os.path.exists(path) else None
 
 
-def measured_traffic():
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes (tools/prof_traffic.sh: separate rocprofv3
-    --pmc runs of FETCH_SIZE and WRITE_SIZE over this very workload, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes
-    for gfx950)."""
-    t = _load(PMC_TRAFFIC)
-    return None if t is None else t.get("k_trace_quad_bytes_per_launch")
+def measured_traffic(frames_per_call, launches_per_call, rel=PMC_CFG3):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (tools/prof_passes.sh: separate rocprofv3
+    --pmc runs of FETCH_SIZE and of WRITE_SIZE over calls of this very shape, FETCH_SIZE doubled as MI355X_MICROARCH.md
+    prescribes for gfx950; tools/prof_summary.py gives the kernel's bytes per frame): x frames per call / launches per call."""
+    j = _load(rel)
+    k = j and j["kernels"].get("k_trace_quad<false>")
+    if not k or "hbm_bytes_per_frame" not in k:
+        return None
+    return float(k["hbm_bytes_per_frame"]) * frames_per_call / max(1, launches_per_call)
 
 
 def measured_valu(rel=PMC_CFG3):
@@ -442,15 +444,21 @@ def main():
     prm = device.make_params(W, H, MAX_REC, part_index=rank, part_count=world, layout=1 if gather else 0)
 
     part_px = device.part_pixels(prm)
-    # 8 frames per call on one GPU (8 x 2.07 M primary rays = one workspace chunk); a rank's share of a frame shrinks with the
-    # rank count, so N GPUs take 8 N frames per call (the library's limit is 64): every rank's launches then carry the rays of
-    # 8 whole frames whatever N is
+    # 32 frames per call on one GPU (32 x 2.07 M primary rays = one workspace chunk of 25 GB): a call is a chain of 14 launches
+    # each as long as its slowest wave (0.3 ms per call whatever it carries, tools/gpu_floor.py), so the more frames a call
+    # carries the less of it every frame pays - 8 / 16 / 32 frames per call: 11 230 / 11 435 / 11 770 Mrays/s
+    # (tools/sweep_bench_chunk.sh).  A rank's share of a frame shrinks with the rank count, so N GPUs take 32 N frames per call
+    # up to the library's limit of 64.
     # ... unless the timed region is shorter than two such calls: a burst of K frames is then traced as two calls of K / 2 in
     # flight together (the second call's kernels fill the gaps of the first one's latency-bound levels, and its gather overlaps):
-    # 20 frames on a rank's eighth of the tiles take 0.076 ms per frame as one call, 0.070 as two (tools/gpu_rank_share.py)
-    B = args.batch if args.batch > 0 else max(1, min(device.MAX_BATCH, 8 * world, (args.steps + 1) // 2))
+    # 20 frames on one GPU: 2 x 10 -> 11 320 Mrays/s, 3 x 7 -> 11 220, 1 x 20 -> 10 820 (tools/sweep_bench_chunk.sh)
+    B_full = min(device.MAX_BATCH, 32 * world)
+    B = args.batch if args.batch > 0 else max(1, min(B_full, (args.steps + 1) // 2))
     if B > device.MAX_BATCH:
         raise SystemExit(f"--batch {B} > {device.MAX_BATCH}")
+    # the shape of call the roofline objects are measured on (counting context, per-launch events, PMC summaries under profiles/):
+    # the full-size call, whatever --steps makes of the timed region
+    B_R = B if (args.batch > 0 or args.rehearse_on_one_gpu) else B_full
     # Every frame has a camera of its own: a small orbit around the model (+-0.12 rad about the y axis at the scene's camera
     # distance, looking at the origin; period 40 frames; frame 0 = the scene's own camera (0,0,5) -> (0,0,-1)).  The cameras are
     # not part of the launch graph the library replays (they travel through its page-locked camera ring), so this is what the
@@ -472,20 +480,17 @@ def main():
     cctx = device.Context(local_rank)
     os.environ["RTHIP_COUNTERS"] = "0"
     cctx.upload(desc)
-    scratch = torch.zeros(B * (part_px if gather else W * H), dtype=torch.int32, device="cuda")
-    cctx.render_batch_device(cam_run(0, B), prm, scratch.data_ptr(), sync=True)
+    scratch = torch.zeros(B_R * (part_px if gather else W * H), dtype=torch.int32, device="cuda")
+    cctx.render_batch_device(cam_run(0, B_R), prm, scratch.data_ptr(), sync=True)
     cst = cctx.stats()
-    aflops = algorithmic_flops(cst)  # per call (the first B cameras of the path)
-    cctx.close()
-    rctx = device.Context(local_rank)  # (ray counts are always collected: a plain context)
-    rctx.upload(desc)
-    path_rays = []                     # this rank's rays of every camera of the path
-    for f in range(PATH):
-        rctx.render_batch_device(cam_run(f, 1), prm, scratch.data_ptr(), sync=True)
-        st1 = rctx.stats()
+    aflops = algorithmic_flops(cst)  # per call (the first B_R cameras of the path)
+    path_rays = []                     # this rank's rays of every camera of the path (on the counting context too: its kernels are
+    for f in range(PATH):              # instantiations of their own, so a kernel trace of this script keeps the timed kernels apart)
+        cctx.render_batch_device(cam_run(f, 1), prm, scratch.data_ptr(), sync=True)
+        st1 = cctx.stats()
         path_rays.append(int(st1.rays_primary + st1.rays_shadow + st1.rays_reflect))
     my_rays_timed = sum(path_rays[f % PATH] for f in range(args.steps))  # exactly the frames of one timed burst
-    rctx.close()
+    cctx.close()
     del scratch
 
     # Timed contexts: `inflight` frames are in flight at once, each on its own context (own HIP stream, own
@@ -569,13 +574,17 @@ def main():
     import threading
     for c in ctxs:
         c.synchronize()
+    for c in ctxs[1:]:  # (their workspaces - 25 GB each at 32 frames per call - make room for the profiling contexts')
+        c.close()
+    del ctxs[1:]        # (what follows uses context 0 only)
+    pouts = [torch.zeros(B_R * (part_px if gather else W * H), dtype=torch.int32, device="cuda") for _ in range(F)]
     os.environ["RTHIP_PROFILE_LAUNCHES"] = "1"
     pctxs = [device.Context(local_rank) for _ in range(F)]
     os.environ["RTHIP_PROFILE_LAUNCHES"] = "0"
     for c in pctxs:
         c.upload(desc)
     for _ in range(3):
-        pctxs[0].render_batch_device(cam_run(0, B), prm, mines[0].data_ptr(), sync=True)
+        pctxs[0].render_batch_device(cam_run(0, B_R), prm, pouts[0].data_ptr(), sync=True)
     st = pctxs[0].stats()
     launch_ms = st.ms_trace / max(1, st.launches_trace)
     kfl, kms = kernel_flops(cst, *material_flops(desc)), kernel_ms(st)
@@ -583,7 +592,7 @@ def main():
 
     def overlapped(j):
         for _ in range(4):
-            pctxs[j].render_batch_device(cam_run(0, B), prm, mines[j].data_ptr(), sync=True)
+            pctxs[j].render_batch_device(cam_run(0, B_R), prm, pouts[j].data_ptr(), sync=True)
             s2 = pctxs[j].stats()
             over.append((s2.ms_trace, s2.launches_trace))
     ths = [threading.Thread(target=overlapped, args=(j,)) for j in range(F)]
@@ -594,6 +603,7 @@ def main():
     launch_ms_overlapped = sum(m for m, _ in over) / max(1, sum(n for _, n in over))
     for c in pctxs:
         c.close()
+    del pouts
 
     # (2) what the reference's own contract costs: ONE frame with nothing else in flight (latency), and the same frame
     #     through rthip_render into page-locked host memory (RenderSync hands back host pixels: D2H-inclusive)
@@ -620,8 +630,6 @@ def main():
                 d2h.append((time.perf_counter() - t1) * 1e3)
             d2h.sort()
             ctxs[0].host_free(pinned)
-    for c in ctxs[1:]:
-        c.close()
     others = {}
     if world == 1 and rank == 0 and not args.no_extras and not args.no_config4:
         cfg4 = config4_line(local_rank)
@@ -634,7 +642,7 @@ def main():
                                                   "dominates), 1920x1080, MaxRecursion 3, lone frames", *scenes.config(3, cam_z=2.2), local_rank)
         if not args.no_config5:
             others["config5"] = config_object("BASELINE configs[4] on ONE GPU: five rotated / scaled 2 097 152-triangle height fields (10 485 760 triangles) + 16 "
-                                              "reflective spheres + checker plane + SkyBox, 7680x4320, MaxRecursion 8, lone frames (two workspace chunks)",
+                                              "reflective spheres + checker plane + SkyBox, 7680x4320, MaxRecursion 8, lone frames (one workspace chunk of 18 GB)",
                                               *scenes.config(5), local_rank, frames=3, hbm_pmc=hbm_roofline(PMC_CFG5))
     red_dev = "cpu" if args.rehearse_on_one_gpu else "cuda"
     rays_t = torch.tensor([float(my_rays_timed), float(path_rays[0])], dtype=torch.float64, device=red_dev)
@@ -653,7 +661,7 @@ def main():
         value = rays_timed / dt / 1e6
         n_launch = max(1, st.launches_trace)
         tflops = (aflops / n_launch) / (launch_ms * 1e-3) / 1e12 if launch_ms > 0 else 0.0
-        traffic = measured_traffic()
+        traffic = measured_traffic(B_R, n_launch)
         hbm_gbs = traffic / (launch_ms * 1e-3) / 1e9 if (traffic and launch_ms > 0) else None
         med = lambda v: v[len(v) // 2] if v else None
         out = {
@@ -688,7 +696,7 @@ def main():
                          "counts_per_call_rank0": {"bvh_steps": int(cst.kd_nodes_visited), "triangle_tests": int(cst.kd_tris_tested),
                                                    "shape_entries": int(cst.shape_tests_full), "shape_entries_rejected_by_ball_test": int(cst.shape_tests - cst.shape_tests_full),
                                                    "rays": int(cst.rays_hard)},
-                         "frames_per_call": B,
+                         "frames_per_call": B_R,
                          "pmc": measured_valu(),
                          # every ray kernel of the timed regime, not only the dominant one: algorithmic flops of one call (the counting
                          # context above) over the kernel's summed launch durations in that call (plain launches alone on the GPU)
@@ -701,8 +709,9 @@ def main():
                          "note": "peak = 78.6 TFLOP/s fp64 vector with FMA; the kernels are built with -ffp-contract=off (bit parity with the "
                                  "non-fused reference), so an instruction is one flop and the usable peak is 39.3 (frac_of_unfused_peak).  "
                                  "`pmc` is the measured side: share of SIMD cycles issuing VALU x active lanes per instruction.  "
-                                 "avg_launch_ms is a launch alone on the GPU; avg_launch_ms_calls_in_flight is the timed region's regime "
-                                 "(what rocprofv3 --stats of `bench.py --no-extras` averages)"},
+                                 "avg_launch_ms is a launch alone on the GPU; avg_launch_ms_calls_in_flight is with as many calls in flight as the timed "
+                                 "region keeps (what rocprofv3 --stats of `bench.py --no-extras` averages); every figure here is for calls of "
+                                 "`frames_per_call` frames, the full-size call, whatever --steps made of the timed region"},
         }
         if cfg4 is not None:
             out["config4"] = cfg4

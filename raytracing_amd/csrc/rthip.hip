@@ -104,7 +104,11 @@ static std::mutex g_scratch_mutex;
 #define RT_SHADE_OCC 4
 #endif
 static const uint32_t kMaxGridQuad = 8192;     // quad kernel (64 rays per workgroup, grid-stride): 16384 costs 2 % when calls overlap, 4096 3 % on a lone 4K frame
-static const size_t kMaxLevelRays = (size_t)1 << 24;  // level-0 rays per chunk (bounds the workspace); RTHIP_CHUNK_RAYS overrides (tests)
+static const size_t kMaxLevelRays = (size_t)1 << 26;  // level-0 rays per chunk; RTHIP_CHUNK_RAYS overrides (tests).  Together with
+static const size_t kMaxWorkspaceBytes = (size_t)32 << 30;  // ... this bound on the per-ray records it sizes the workspace for 288 GB of
+                                                      // HBM: 32 frames of 1080p (or one 8K frame at MaxRecursion 8) are ONE chunk - a
+                                                      // call's fixed cost (a chain of launches, each as long as its slowest wave) is
+                                                      // paid once per chunk: 8-frame chunks (2^24) cost the bench 5 %
 static const uint32_t kMaxGridLevel = 4096;   // k_trace_easy / k_shade / k_trace: grid-stride over a bounded grid (one workgroup per 256 rays
                                               // costs 6 % when calls overlap: LDS table staging, statistics flush and launch per workgroup)
 static const uint32_t kShadeCountShapes = 64;                      // per-shape hit counters of a counting context (shapes beyond share the last)
@@ -1481,6 +1485,7 @@ struct rthip_ctx {
     int count_kd = 0;
     uint32_t last_frames = 1;  // frames of the last render call (statistics are per call)
     size_t chunk_rays = kMaxLevelRays;
+    bool chunk_rays_forced = false;  // RTHIP_CHUNK_RAYS given: taken as it is
     // one frame = ~20 dependent launches; replaying them as a HIP graph cuts the host cost of a frame from ~80 us to
     // one launch (what bounds small frames and the per-GPU share of a multi-GPU frame).  The graph is re-captured
     // when anything baked into it changes (params, frames per call, output pointers, scene, workspace) - but only once the
@@ -1561,7 +1566,7 @@ int rthip_create(int device, rthip_ctx **out) {
     env = getenv("RTHIP_GRAPH");
     if (env && atoi(env) == 0) c->graphs_enabled = false;
     env = getenv("RTHIP_CHUNK_RAYS");
-    if (env && atoll(env) > 0) c->chunk_rays = (size_t)atoll(env);
+    if (env && atoll(env) > 0) { c->chunk_rays = (size_t)atoll(env); c->chunk_rays_forced = true; }
     env = getenv("RTHIP_PROFILE_LAUNCHES");
     c->profile_launches = env && atoi(env) != 0;
     memset(&c->sv, 0, sizeof c->sv);
@@ -2116,7 +2121,9 @@ static int render_frame(rthip_ctx *c, const rthip_camera *cam, uint32_t n_frames
     const uint32_t per_tile = fp.tile_w * fp.tile_h;
     const uint32_t spp = fp.aa ? 9 : 1;
     const uint32_t levels = fp.max_rec + 1;
-    uint32_t tiles_per_chunk = (uint32_t)(c->chunk_rays / ((size_t)per_tile * spp));
+    size_t chunk_rays = c->chunk_rays;
+    if (!c->chunk_rays_forced) chunk_rays = std::min(chunk_rays, kMaxWorkspaceBytes / (36 * (size_t)levels + 216));
+    uint32_t tiles_per_chunk = (uint32_t)(chunk_rays / ((size_t)per_tile * spp));
     if (tiles_per_chunk == 0) tiles_per_chunk = 1;
     if (tiles_per_chunk > my_tiles) tiles_per_chunk = my_tiles ? my_tiles : 1;
     const size_t N = (size_t)tiles_per_chunk * per_tile * spp;
@@ -2153,7 +2160,7 @@ static int render_frame(rthip_ctx *c, const rthip_camera *cam, uint32_t n_frames
         // the same records, one after the other in this GPU's `scratch` array (256-byte aligned each)
         if (tiles_per_chunk < my_tiles)
             return fail(RTHIP_E_UNSUPPORTED, "rthip_render_device_noalloc: %ux%u (x%u frames%s) is %zu level-0 rays, more than one workspace chunk (%zu)",
-                        p->width, p->height, n_frames, fp.aa ? ", SSAA" : "", (size_t)my_tiles * per_tile * spp, c->chunk_rays);
+                        p->width, p->height, n_frames, fp.aa ? ", SSAA" : "", (size_t)my_tiles * per_tile * spp, chunk_rays);
         unsigned char *base = c->device < kMaxDevices ? (unsigned char *)g_scratch_ptr[c->device] : nullptr;
         if (!base) return fail(RTHIP_E_STATE, "rthip_render_device_noalloc: no scratch address for device %d", c->device);
         size_t off = 0;
