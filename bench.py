@@ -453,7 +453,7 @@ def main():
     # flight together (the second call's kernels fill the gaps of the first one's latency-bound levels, and its gather overlaps):
     # 20 frames on one GPU: 2 x 10 -> 11 320 Mrays/s, 3 x 7 -> 11 220, 1 x 20 -> 10 820 (tools/sweep_bench_chunk.sh)
     B_full = min(device.MAX_BATCH, 32 * world)
-    B = args.batch if args.batch > 0 else max(1, min(B_full, (args.steps + 1) // 2))
+    B = args.batch if args.batch > 0 else max(1, min(B_full, (args.steps + 1) // 2))  # (200 frames: 6 x 32 + 8 beats 8 x 23 + 16 and 6 x 29 + 26)
     if B > device.MAX_BATCH:
         raise SystemExit(f"--batch {B} > {device.MAX_BATCH}")
     # the shape of call the roofline objects are measured on (counting context, per-launch events, PMC summaries under profiles/):

@@ -103,7 +103,7 @@ static std::mutex g_scratch_mutex;
 #ifndef RT_SHADE_OCC
 #define RT_SHADE_OCC 4
 #endif
-static const uint32_t kMaxGridQuad = 8192;     // quad kernel (64 rays per workgroup, grid-stride): 16384 costs 2 % when calls overlap, 4096 3 % on a lone 4K frame
+static const uint32_t kMaxGridQuad = 16384;    // quad kernel (64 rays per workgroup, grid-stride): 8192 costs 1.3 % on a lone 4K frame, 4096 5 %; calls of 32 frames do not care (tools/sweep_grids.sh)
 static const size_t kMaxLevelRays = (size_t)1 << 26;  // level-0 rays per chunk; RTHIP_CHUNK_RAYS overrides (tests).  Together with
 static const size_t kMaxWorkspaceBytes = (size_t)32 << 30;  // ... this bound on the per-ray records it sizes the workspace for 288 GB of
                                                       // HBM: 32 frames of 1080p (or one 8K frame at MaxRecursion 8) are ONE chunk - a
@@ -2207,6 +2207,8 @@ static int render_frame(rthip_ctx *c, const rthip_camera *cam, uint32_t n_frames
     // cannot overflow, see quad::Stack: the deepest node is bvh_depth levels below the root, so a path makes bvh_depth + 1 steps
     // of at most three pushes (3 * depth + 1 was one level short: a mesh whose BVH is a lone root overflowed with two pushes)
     const uint32_t quad_cap = 3 * (c->bvh_depth + 1);
+    static const uint32_t max_grid_level = [] { const char *e = getenv("RTHIP_GRID_LEVEL"); return e && atoi(e) > 0 ? (uint32_t)atoi(e) : kMaxGridLevel; }();  // (tuning)
+    static const uint32_t max_grid_quad = [] { const char *e = getenv("RTHIP_GRID_QUAD"); return e && atoi(e) > 0 ? (uint32_t)atoi(e) : kMaxGridQuad; }();
     const size_t lds_quad = (size_t)quad::park_offset(quad_cap) + (size_t)quad::kRaysPerBlock * quad::kParkStride;
     if (lds_quad > 48 * 1024) {
         HIP_TRY(hipFuncSetAttribute((const void *)k_trace_quad<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_quad));
@@ -2290,7 +2292,7 @@ static int render_frame(rthip_ctx *c, const rthip_camera *cam, uint32_t n_frames
                                kCounterSlots * kCounterStride, (uint32_t *)nullptr, 0u, (uint32_t *)nullptr, 0u);
         for (uint32_t level = 0; level < levels; level++) {
             uint32_t grid = (fp.N0 + kBlock - 1) / kBlock;
-            if (grid > kMaxGridLevel) grid = kMaxGridLevel;  // every level: the kernels stride over their rays (see kMaxGridLevel)
+            if (grid > max_grid_level) grid = max_grid_level;  // every level: the kernels stride over their rays (see kMaxGridLevel)
             hipEvent_t ea = nullptr, eq = nullptr, eb = nullptr, ec = nullptr;
             if (profile) {
                 if (get_event(&ea) || get_event(&eq) || get_event(&eb) || get_event(&ec)) return RTHIP_E_HIP;
@@ -2306,7 +2308,7 @@ static int render_frame(rthip_ctx *c, const rthip_camera *cam, uint32_t n_frames
                 if (profile) HIP_TRY(hipEventRecord(eq, c->stream));
                 if (c->has_meshes) {  // the rays that need a mesh walk (count on the device: the grid is an upper bound, strided)
                     uint32_t qgrid = (fp.N0 + quad::kRaysPerBlock - 1) / quad::kRaysPerBlock;
-                    if (qgrid > kMaxGridQuad) qgrid = kMaxGridQuad;
+                    if (qgrid > max_grid_quad) qgrid = max_grid_quad;
                     if (c->count_kd)
                         hipLaunchKernelGGL((k_trace_quad<true>), dim3(qgrid), dim3(kBlock), lds_quad, c->stream, c->sv, fp, w, level, quad_cap);
                     else

@@ -44,6 +44,7 @@ def load_host():
         L.rehost_render_moved.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.POINTER(C.c_int)]
         L.rehost_render_flip_normal_mode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
         L.rehost_render_path.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.rehost_raycast.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p]
         _host = sb
     return _host
 
@@ -131,6 +132,15 @@ class HostScene:
         if rc != 0:
             raise RuntimeError(f"rehost_render_path failed ({rc}): " + self.L.rehost_last_error().decode())
         return px
+
+    def raycast(self, rays, max_recursion=3):
+        """HipRaytracer::Raycast, one call per ray of `rays` ([n, 6]: origin, direction) -> [n, 3] colours"""
+        rays = np.ascontiguousarray(rays, dtype=np.float64).reshape(-1, 6)
+        rgb = np.zeros((len(rays), 3), np.float64)
+        rc = self.L.rehost_raycast(self.h, max_recursion, len(rays), rays.ctypes.data_as(C.c_void_p), rgb.ctypes.data_as(C.c_void_p))
+        if rc != 0:
+            raise RuntimeError(f"rehost_raycast failed ({rc}): " + self.L.rehost_last_error().decode())
+        return rgb
 
     def render_flip_normal_mode(self, width, height, max_recursion=3):
         """Two frames through ONE HipRaytracer; between them Mesh::NormalMode of every mesh flips (Face <-> Vertex).  Returns

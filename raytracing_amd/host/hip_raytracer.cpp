@@ -46,8 +46,45 @@ HipRaytracer::~HipRaytracer() {
     else if (m_Ctx) rthip_destroy(m_Ctx);
 }
 
-Color HipRaytracer::Raycast(Scene *, const Ray &) {
-    throw DeviceError(RTHIP_E_UNSUPPORTED, "HipRaytracer shades whole frames on the device; per-ray host Raycast does not exist");
+// Raytracer::Raycast (Raytracer.cpp:312-315) for ONE ray, on the device: the scene goes up as for a frame (or stays, when it is the
+// one already there) and the ray runs through the same device functions a frame's rays do (rthip_probe_raycast).  A single ray
+// costs a launch and a round trip - the reference calls this per pixel from its worker threads, this class renders frames with
+// Render instead and keeps Raycast for callers that want the colour along one ray (picking, probes, tests).
+Color HipRaytracer::Raycast(Scene *scene, const Ray &ray) {
+    if (RendererKind() != RTHIP_RENDER_RAYTRACER)
+        throw DeviceError(RTHIP_E_UNSUPPORTED, "HipDebugRaycaster renders whole frames on the device; it has no per-ray Raycast");
+    {
+        std::unique_lock<std::mutex> lock(m_Mutex);
+        m_Idle.wait(lock, [this] { return !m_Busy; });
+        m_Busy = true;
+        EnsureContext();
+    }
+    int rc = 0;
+    std::string err;
+    HipRenderStats stats;
+    double c[3] = {0, 0, 0};
+    try {
+        rc = PrepareScene(scene, stats, err);
+        if (!rc) {
+            const double o[3] = {ray.Origin.X, ray.Origin.Y, ray.Origin.Z}, d[3] = {ray.Direction.X, ray.Direction.Y, ray.Direction.Z};
+            rc = rthip_probe_raycast(m_Ctx, MaxRecursion, 1, o, d, c);
+            if (rc) err = rthip_last_error();
+        }
+    } catch (const std::exception &e) {
+        rc = RTHIP_E_INVALID;
+        err = e.what();
+    }
+    {
+        std::lock_guard<std::mutex> lock(m_Mutex);
+        m_Busy = false;
+        m_Idle.notify_all();
+    }
+    if (rc) throw DeviceError(rc, err);
+    Color out;  // (the device colour is already clamped: no constructor in between)
+    out.R = c[0];
+    out.G = c[1];
+    out.B = c[2];
+    return out;
 }
 
 void HipRaytracer::Interrupt() {

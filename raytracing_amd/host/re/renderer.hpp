@@ -104,8 +104,11 @@ public:
     void Interrupt() override;
     RenderStatus GetStatus() override;
     HipRenderStats GetLastStats();
+    // additive: AbstractRaycaster::Raycast is protected (Raytracer.h:78); this is the same call for users of the class
+    Color RaycastSync(Scene *scene, const Ray &ray) { return Raycast(scene, ray); }
 protected:
-    // The abstract base requires it; the device path shades whole frames, never single rays on the host.
+    // Raytracer::Raycast (Raytracer.cpp:312-315): the colour along ONE ray, traced and shaded on the device (frames go through
+    // Render, never through this)
     Color Raycast(Scene *scene, const Ray &ray) override;
     virtual int RendererKind() const { return 0; }  // RTHIP_RENDER_RAYTRACER
 private:

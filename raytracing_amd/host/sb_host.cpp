@@ -423,6 +423,32 @@ int rehost_render_path(sb_scene *s, const sb_render_params *p, int n, const doub
     }
 }
 
+// HipRaytracer::Raycast for n rays, one call each (origin xyz, direction xyz per ray) -> n unpacked colours
+int rehost_raycast(sb_scene *s, uint32_t max_recursion, int n, const double *rays6, double *rgb) {
+    try {
+        HipRaytracer rt(64, 64);
+        rt.MaxRecursion = max_recursion;
+        rt.Device = s->device;
+        rt.UseReferenceKdTree = s->use_kd != 0;
+        for (int i = 0; i < n; i++) {
+            Ray r;
+            r.Origin = V3(rays6 + 6 * i);
+            r.Direction = V3(rays6 + 6 * i + 3);
+            const Color c = rt.RaycastSync(s->scene.get(), r);
+            rgb[3 * i] = c.R; rgb[3 * i + 1] = c.G; rgb[3 * i + 2] = c.B;
+        }
+        s->compiled = false;
+        s->uploaded = false;
+        return 0;
+    } catch (const DeviceError &e) {
+        g_host_err = e.what();
+        return e.Code;
+    } catch (const std::exception &e) {
+        g_host_err = e.what();
+        return RTHIP_E_INVALID;
+    }
+}
+
 // Two frames through ONE renderer with Mesh::NormalMode of every mesh flipped (Face <-> Vertex) in between: a public field
 // the reference reads live per hit (Scene.cpp:456) and whose change does not invalidate the mesh.  Returns the second
 // frame and whether the geometry stayed on the device.  The scene keeps the flipped modes.

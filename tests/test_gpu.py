@@ -639,3 +639,16 @@ def test_c_abi_error_reporting(ctx):
     with pytest.raises(device.RthipError):
         device.Context(1 << 20)
     fresh.close()
+
+
+def test_hip_raytracer_raycast_answers_single_rays(golden):
+    """re::HipRaytracer::Raycast(scene, ray) (the virtual every AbstractRaycaster has, Raytracer.h:78): one ray at a time through
+    the renderer class - scene compiled, flattened and uploaded by the first call, kept for the following ones - gives the
+    genuine Raytracer::Raycast's colours of the golden vectors (bunny + checker plane + SkyBox: mesh hits, plane, sky, bounces)."""
+    k = golden["kat"]
+    hs = host.HostScene(KAT_SCENES["cfg3"]())
+    o, d = k["cfg3_ray_o"], k["cfg3_ray_d"]
+    pick = np.linspace(0, len(o) - 1, 24).astype(int)
+    got = hs.raycast(np.concatenate([o[pick], d[pick]], axis=1), 3)
+    assert np.array_equal(got, k["cfg3_raycast"][pick])
+    assert len(np.unique(got.round(6), axis=0)) > 5, "the picked rays all see the same thing"
