@@ -1108,9 +1108,13 @@ __global__ __launch_bounds__(kBlock, RT_EASY_OCC) void k_trace_easy(SceneView sv
 // Stage 1b of a level for the BVH path (accel = 0): the rays k_trace_easy listed as needing a mesh walk,
 // four lanes per ray, see namespace quad.  Rays the quad walk cannot finish (degenerate (ray, mesh) pairs,
 // stack overflow) go to the redo list and are re-traced by the redo instantiation of k_trace.
-template <bool COUNT>
-__global__ __launch_bounds__(kBlock, RT_QUAD_OCC) void k_trace_quad(SceneView sv, FrameParams fp, Work w, uint32_t level,
-                                                                     uint32_t stack_cap) {
+// OCC: waves per SIMD the kernel is compiled for.  5 (95 VGPRs, 2 spilled) is the default.  6 (80 VGPRs, 27 spilled outside the
+// walk loop) is an opt-in (RTHIP_QUAD_OCC6=1): ONE mesh of millions of triangles, whose steps wait for HBM / MALL, gains from the sixth
+// resident wave (config 4: 12.98 -> 12.68 ms); the spills are paid per (ray, mesh) entry, so five such meshes lose (config 5:
+// 133.8 -> 139.3 ms), and a tree that stays in L2 has nothing to hide (config 3: +3.5 %).  profiles/r03_experiment_quad_occ6.txt
+template <bool COUNT, int OCC = RT_QUAD_OCC>
+__global__ __launch_bounds__(kBlock, OCC) void k_trace_quad(SceneView sv, FrameParams fp, Work w, uint32_t level,
+                                                            uint32_t stack_cap) {
     const uint32_t q = threadIdx.x & 3u, g = threadIdx.x >> 2;
     quad::Stack qs;
     qs.cap = stack_cap;
@@ -2207,12 +2211,15 @@ static int render_frame(rthip_ctx *c, const rthip_camera *cam, uint32_t n_frames
     // cannot overflow, see quad::Stack: the deepest node is bvh_depth levels below the root, so a path makes bvh_depth + 1 steps
     // of at most three pushes (3 * depth + 1 was one level short: a mesh whose BVH is a lone root overflowed with two pushes)
     const uint32_t quad_cap = 3 * (c->bvh_depth + 1);
+    // the quad kernel's occupancy variant (opt-in, RTHIP_QUAD_OCC6=1): see k_trace_quad
+    static const bool quad_occ6 = [] { const char *e = getenv("RTHIP_QUAD_OCC6"); return e && atoi(e) != 0; }();
     static const uint32_t max_grid_level = [] { const char *e = getenv("RTHIP_GRID_LEVEL"); return e && atoi(e) > 0 ? (uint32_t)atoi(e) : kMaxGridLevel; }();  // (tuning)
     static const uint32_t max_grid_quad = [] { const char *e = getenv("RTHIP_GRID_QUAD"); return e && atoi(e) > 0 ? (uint32_t)atoi(e) : kMaxGridQuad; }();
     const size_t lds_quad = (size_t)quad::park_offset(quad_cap) + (size_t)quad::kRaysPerBlock * quad::kParkStride;
     if (lds_quad > 48 * 1024) {
         HIP_TRY(hipFuncSetAttribute((const void *)k_trace_quad<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_quad));
         HIP_TRY(hipFuncSetAttribute((const void *)k_trace_quad<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_quad));
+        HIP_TRY(hipFuncSetAttribute((const void *)k_trace_quad<false, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_quad));
     }
     const size_t lds_tables = (size_t)c->n_tables * 256;
 
@@ -2311,6 +2318,8 @@ static int render_frame(rthip_ctx *c, const rthip_camera *cam, uint32_t n_frames
                     if (qgrid > max_grid_quad) qgrid = max_grid_quad;
                     if (c->count_kd)
                         hipLaunchKernelGGL((k_trace_quad<true>), dim3(qgrid), dim3(kBlock), lds_quad, c->stream, c->sv, fp, w, level, quad_cap);
+                    else if (quad_occ6)
+                        hipLaunchKernelGGL((k_trace_quad<false, 6>), dim3(qgrid), dim3(kBlock), lds_quad, c->stream, c->sv, fp, w, level, quad_cap);
                     else
                         hipLaunchKernelGGL((k_trace_quad<false>), dim3(qgrid), dim3(kBlock), lds_quad, c->stream, c->sv, fp, w, level, quad_cap);
                 }
