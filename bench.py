@@ -11,14 +11,14 @@ assemble kernel go round the ranks (--gather-dst 0: always rank 0; --collective 
 into the frames on that rank's device; total work
 is fixed as N grows ("strong" scaling).
 
-Frames are traced in runs: one rthip_render_batch_device call takes --batch frames (default 8 per GPU: 8, 16, 32, 64 on 1, 2, 4, 8 GPUs; the same camera for
-all of them here, but every frame is traced in full — nothing is reused between frames) through ONE set of kernel
+Frames are traced in runs: one rthip_render_batch_device call takes --batch frames (default 32 per GPU up to the library's 64 per call - or half the
+timed burst when that is shorter; every frame has a camera of its own and is traced in full — nothing is reused between frames) through ONE set of kernel
 launches, and --inflight calls (default 3) are in flight on separate HIP streams.  A run of frames is what a camera
 path rendered ahead of time looks like; it is also what keeps a GPU busy when its share of a 1080p frame is an
 eighth of it (a frame is ~20 dependent launches, each of them latency-bound on so few rays).  --steps K times exactly
 K frames: K // batch full calls and one shorter call.  --latency also reports the latency of a single frame.
 
-Prints ONE JSON line (rank 0).  Extra objects: "roofline" (dominant kernel k_trace_quad: algorithmic VALU flops from
+Prints ONE JSON line (rank 0).  Extra objects: "roofline" (dominant kernel - the one that walks the meshes, k_trace_coop on this scene: algorithmic VALU flops from
 SURVEY.md §8d's per-unit weights x counts measured on this call, against the fp64 vector peak; the HBM fraction next to it
 from the PMC-measured traffic), "config4" (BASELINE configs[3], the 2 M-triangle 4K frame: the config whose roof IS HBM),
 "single_frame_latency_ms" / "ms_per_frame_with_d2h" in "config", and "cpu_baseline" (the genuine reference compiled in
@@ -55,7 +55,7 @@ def _newest(*names):
     return os.path.join("profiles", names[0])
 
 
-PMC_CFG3 = _newest("r03_pmc_summary_config3_batch32.json", "r03_pmc_summary_config3_batch8.json", "r02_pmc_summary_config3_batch8.json")
+PMC_CFG3 = _newest("r03d_pmc_summary_config3_batch32.json", "r03_pmc_summary_config3_batch32.json", "r03_pmc_summary_config3_batch8.json", "r02_pmc_summary_config3_batch8.json")
 PMC_CFG4 = _newest("r03_pmc_summary_config4.json", "r02_pmc_summary_config4.json")
 PMC_CFG5 = _newest("r03_pmc_summary_config5.json")
 
@@ -100,25 +100,31 @@ def material_flops(desc_ptr):
     return per_shape, (FLOPS_SKY if bg == 2 else 0)
 
 
-def kernel_flops(st, mat, sky):
+def walk_kernel(ctx):
+    """the kernel that walks the meshes for this context's scene: k_trace_coop (per-ray work one ray per lane, up to 64 rays per wave;
+    scenes whose trees stay in L2, lists of >= 300 000 rays) or k_trace_quad (everything of a ray in its quad: big trees, short lists).
+    Both are launched for a small-tree scene and one returns at once; the times below bracket the pair."""
+    return "k_trace_coop" if ctx.upload_info().walk_coop else "k_trace_quad"
+
+
+def kernel_flops(st, mat, sky, walk="k_trace_quad"):
     """algorithmic flops of one call, by kernel, from the statistics of a counting context"""
     shaded = lambda k: sum(int(st.shape_hits[k][i]) * mat[min(i, len(mat) - 1)] for i in range(64) if st.shape_hits[k][i]) if mat else 0
     shading = lambda k: shaded(k) + sky * int(st.background_evals[k]) + FLOPS_LIGHT * int(st.rays_shadow_by_kernel[k]) + FLOPS_REFLECT * int(st.rays_reflect_by_kernel[k])
-    return {"k_trace_quad": int(algorithmic_flops(st)),
+    return {walk: int(algorithmic_flops(st)),
             "k_trace_easy": int(FLOPS_RAYGEN * st.rays_primary + shape_flops(st.shape_tests_easy, st.shape_tests_easy_full) + shading(0)),
             "k_shade": int(shading(1))}
 
 
-def kernel_ms(st):
+def kernel_ms(st, walk="k_trace_quad"):
     """summed duration of each kernel over the levels of one call (a context created with RTHIP_PROFILE_LAUNCHES=1: HIP events around
     plain launches that have the GPU to themselves)"""
     n = max(1, st.launches_trace)
-    return {"k_trace_quad": float(st.ms_trace), "k_trace_easy": float(st.ms_easy), "k_shade": float(sum(st.level_ms_shade[i] for i in range(min(n, 17))))}
+    return {walk: float(st.ms_trace), "k_trace_easy": float(st.ms_easy), "k_shade": float(sum(st.level_ms_shade[i] for i in range(min(n, 17))))}
 
 
 def measured_pmc(kernel, rel):
-    j = _load(rel)
-    k = j and j["kernels"].get(kernel)
+    k = _pmc_kernel(_load(rel), kernel)
     if not k:
         return None
     out = {key: k[key] for key in ("valu_issue_util", "wave_time_waiting", "l2_hit_rate", "active_lanes_per_valu_inst", "valu_insts_per_frame") if key in k}
@@ -158,6 +164,7 @@ def config_object(workload, sd, kw, local_rank, frames=5, hbm_pmc=None):
     ctx.synchronize()
     t2 = time.perf_counter()
     up = ctx.upload_info()
+    walk = "k_trace_quad" + (" / k_trace_coop" if up.walk_coop else "")  # (a lone frame's short lists go through k_trace_quad either way)
     for _ in range(3):
         ctx.render_device(cam, prm, fb.data_ptr(), sync=True)
     st = ctx.stats()
@@ -182,7 +189,7 @@ def config_object(workload, sd, kw, local_rank, frames=5, hbm_pmc=None):
         c.render_device(cam, prm, fb.data_ptr(), sync=True)
     pst = c.stats()
     c.close()
-    fl, kms = kernel_flops(cst, mat, sky), kernel_ms(pst)
+    fl, kms = kernel_flops(cst, mat, sky, walk), kernel_ms(pst, walk)
     total = sum(fl.values())
     tf = total / (ms * 1e-3) / 1e12
     out = {"workload": workload, "rays_per_frame": rays, "ms_per_frame": ms, "ms_per_frame_samples": ts, "ms_per_synchronous_call": wall[len(wall) // 2],
@@ -192,7 +199,7 @@ def config_object(workload, sd, kw, local_rank, frames=5, hbm_pmc=None):
            "trees": {"kd_built_on": "device" if up.kd_meshes else "host", "kd_device_ms": up.kd_device_ms, "bvh_built_on": "device" if up.bvh_meshes else "host"},
            "roofline": {"bound": "valu_fp64", "achieved": tf, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_VALU_PEAK_TFLOPS,
                         "frac_of_unfused_peak": tf / FP64_VALU_PEAK_UNFUSED_TFLOPS, "algorithmic_flops_per_frame": total, "traffic": None,
-                        "note": "whole frame: algorithmic flops of k_trace_easy + k_trace_quad + k_shade over the frame's wall time",
+                        "note": "whole frame: algorithmic flops of k_trace_easy + the walk kernel + k_shade over the frame's wall time",
                         "kernels": [{"kernel": k, "algorithmic_flops_per_frame": fl[k], "ms_per_frame": kms[k],
                                      "achieved": (fl[k] / (kms[k] * 1e-3) / 1e12) if kms[k] > 0 else None,
                                      "frac": (fl[k] / (kms[k] * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS) if kms[k] > 0 else None} for k in fl],
@@ -213,25 +220,39 @@ def _load(rel):
     return json.load(open(path)) if os.path.exists(path) else None
 
 
-def measured_traffic(frames_per_call, launches_per_call, rel=PMC_CFG3):
+def _pmc_kernel(j, name):
+    """the entry of a kernel instantiation in a PMC summary (`name` like "k_trace_coop<false>"; the profiler may spell out more
+    template arguments)"""
+    if not j:
+        return None
+    ks = j["kernels"]
+    if name in ks:
+        return ks[name]
+    stem = name.rstrip(">")
+    for k in sorted(ks):
+        if k.startswith(stem + ",") or k.startswith(stem + ">"):
+            return ks[k]
+    return None
+
+
+def measured_traffic(frames_per_call, launches_per_call, rel=PMC_CFG3, kernel="k_trace_quad"):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes (tools/prof_passes.sh: separate rocprofv3
     --pmc runs of FETCH_SIZE and of WRITE_SIZE over calls of this very shape, FETCH_SIZE doubled as MI355X_MICROARCH.md
     prescribes for gfx950; tools/prof_summary.py gives the kernel's bytes per frame): x frames per call / launches per call."""
-    j = _load(rel)
-    k = j and j["kernels"].get("k_trace_quad<false>")
+    k = _pmc_kernel(_load(rel), kernel + "<false>")
     if not k or "hbm_bytes_per_frame" not in k:
         return None
     return float(k["hbm_bytes_per_frame"]) * frames_per_call / max(1, launches_per_call)
 
 
-def measured_valu(rel=PMC_CFG3):
+def measured_valu(rel=PMC_CFG3, kernel="k_trace_quad"):
     """VALU issue utilisation / active lanes / waiting fraction of the dominant kernel from the committed PMC passes over the
     bench's own shape of work (`tools/prof_passes.sh <tag> 3 4 8` + prof_summary.py): the measured side of the VALU roof."""
     src = rel
     j = _load(src)
     if j is None:
         return None
-    k = j["kernels"].get("k_trace_quad<false>")
+    k = _pmc_kernel(j, kernel + "<false>")
     if k is None:
         return None
     out = {key: k[key] for key in ("valu_issue_util", "wave_time_waiting", "l2_hit_rate", "active_lanes_per_valu_inst") if key in k}
@@ -278,8 +299,7 @@ def cpu_baseline(sd, frames=5):
 def hbm_roofline(pmc_rel, kernel="k_trace_quad<false>"):
     """HBM roof of a kernel from a committed PMC summary: bytes per frame (FETCH_SIZE x 2 + WRITE_SIZE, separate passes) over the
     kernel's own time in the same passes"""
-    pmc = _load(pmc_rel)
-    k = pmc and pmc["kernels"].get(kernel)
+    k = _pmc_kernel(_load(pmc_rel), kernel)
     if not (k and k.get("hbm_bytes_per_frame")):
         return None
     gbs = k["hbm_bytes_per_frame"] / (k["gpu_ms_per_frame_serialised"] * 1e-3) / 1e9
@@ -586,8 +606,9 @@ def main():
     for _ in range(3):
         pctxs[0].render_batch_device(cam_run(0, B_R), prm, pouts[0].data_ptr(), sync=True)
     st = pctxs[0].stats()
+    walk = walk_kernel(pctxs[0])
     launch_ms = st.ms_trace / max(1, st.launches_trace)
-    kfl, kms = kernel_flops(cst, *material_flops(desc)), kernel_ms(st)
+    kfl, kms = kernel_flops(cst, *material_flops(desc), walk), kernel_ms(st, walk)
     over = []
 
     def overlapped(j):
@@ -661,7 +682,7 @@ def main():
         value = rays_timed / dt / 1e6
         n_launch = max(1, st.launches_trace)
         tflops = (aflops / n_launch) / (launch_ms * 1e-3) / 1e12 if launch_ms > 0 else 0.0
-        traffic = measured_traffic(B_R, n_launch)
+        traffic = measured_traffic(B_R, n_launch, kernel=walk)
         hbm_gbs = traffic / (launch_ms * 1e-3) / 1e9 if (traffic and launch_ms > 0) else None
         med = lambda v: v[len(v) // 2] if v else None
         out = {
@@ -688,7 +709,7 @@ def main():
                          "traffic": traffic,
                          "hbm": {"achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (hbm_gbs / HBM_PEAK_GBS) if hbm_gbs else None,
                                  "note": "PMC-measured HBM bytes per launch (`traffic`) / avg_launch_ms"},
-                         "kernel": "k_trace_quad", "launches_per_call": int(st.launches_trace), "avg_launch_ms": launch_ms,
+                         "kernel": walk, "launches_per_call": int(st.launches_trace), "avg_launch_ms": launch_ms,
                          "avg_launch_ms_calls_in_flight": launch_ms_overlapped,
                          "algorithmic_flops_per_call_rank0": int(aflops),
                          "flop_weights": {"bvh_step_4_boxes_fp32": FLOPS_NODE, "triangle_test_fp64": FLOPS_TRI, "shape_entry_fp64": FLOPS_SHAPE,
@@ -697,7 +718,7 @@ def main():
                                                    "shape_entries": int(cst.shape_tests_full), "shape_entries_rejected_by_ball_test": int(cst.shape_tests - cst.shape_tests_full),
                                                    "rays": int(cst.rays_hard)},
                          "frames_per_call": B_R,
-                         "pmc": measured_valu(),
+                         "pmc": measured_valu(kernel=walk),
                          # every ray kernel of the timed regime, not only the dominant one: algorithmic flops of one call (the counting
                          # context above) over the kernel's summed launch durations in that call (plain launches alone on the GPU)
                          "kernels": [{"kernel": k, "algorithmic_flops_per_call": kfl[k], "ms_per_call": kms[k], "launches_per_call": int(st.launches_trace),

@@ -104,6 +104,8 @@ static std::mutex g_scratch_mutex;
 #define RT_SHADE_OCC 4
 #endif
 static const uint32_t kMaxGridQuad = 16384;    // quad kernel (64 rays per workgroup, grid-stride): 8192 costs 1.3 % on a lone 4K frame, 4096 5 %; calls of 32 frames do not care (tools/sweep_grids.sh)
+static const uint32_t kMaxGridCoop = 4096;     // k_trace_coop (up to 256 rays per workgroup and stride): on a short list the launch returns at once, and 16384 idle
+                                               // workgroups cost a lone frame 10 us over its four levels; 32-frame calls: 2048 / 4096 / 8192 / 16384 = 12 385 / 12 467 / 12 398 / 12 270 Mrays/s
 static const size_t kMaxLevelRays = (size_t)1 << 26;  // level-0 rays per chunk; RTHIP_CHUNK_RAYS overrides (tests).  Together with
 static const size_t kMaxWorkspaceBytes = (size_t)32 << 30;  // ... this bound on the per-ray records it sizes the workspace for 288 GB of
                                                       // HBM: 32 frames of 1080p (or one 8K frame at MaxRecursion 8) are ONE chunk - a
@@ -1112,9 +1114,8 @@ __global__ __launch_bounds__(kBlock, RT_EASY_OCC) void k_trace_easy(SceneView sv
 // walk loop) is an opt-in (RTHIP_QUAD_OCC6=1): ONE mesh of millions of triangles, whose steps wait for HBM / MALL, gains from the sixth
 // resident wave (config 4: 12.98 -> 12.68 ms); the spills are paid per (ray, mesh) entry, so five such meshes lose (config 5:
 // 133.8 -> 139.3 ms), and a tree that stays in L2 has nothing to hide (config 3: +3.5 %).  profiles/r03_experiment_quad_occ6.txt
-template <bool COUNT, int OCC = RT_QUAD_OCC>
-__global__ __launch_bounds__(kBlock, OCC) void k_trace_quad(SceneView sv, FrameParams fp, Work w, uint32_t level,
-                                                            uint32_t stack_cap) {
+template <bool COUNT>
+__device__ __forceinline__ void quad_body(const SceneView &sv, const FrameParams &fp, const Work &w, uint32_t level, uint32_t stack_cap) {
     const uint32_t q = threadIdx.x & 3u, g = threadIdx.x >> 2;
     quad::Stack qs;
     qs.cap = stack_cap;
@@ -1179,7 +1180,325 @@ __global__ __launch_bounds__(kBlock, OCC) void k_trace_quad(SceneView sv, FrameP
     }
     if (COUNT) trace_counters_flush(fp, w, kc, max_ray_nodes, t_start);
 }
+// n_coop: lists of this length and longer are k_trace_coop's (launched right behind this kernel when the scene's trees are
+// small; 0xffffffff otherwise)
+template <bool COUNT, int OCC = RT_QUAD_OCC>
+__global__ __launch_bounds__(kBlock, OCC) void k_trace_quad(SceneView sv, FrameParams fp, Work w, uint32_t level,
+                                                            uint32_t stack_cap, uint32_t n_coop) {
+    if (min(w.N, w.hard_count[0]) >= n_coop) return;
+    quad_body<COUNT>(sv, fp, w, level, stack_cap);
+}
 
+// ---------------------------------------------------------------------------- hard rays, up to 64 per wave
+// k_trace_quad does everything of a hard ray in the four lanes of its quad, so whatever is per-RAY work - the world -> local
+// transforms, the hit record of the winner, the shadow rays' set-up and their analytic shapes - is issued for 16 rays per wave
+// with each value computed four times over: on the bunny ~1 000 of the ~2 600 VALU instructions a wave issues.  Here a wave
+// takes up to 64 rays, ONE RAY PER LANE for all of that, and only the mesh walks run four lanes per ray: the lanes whose ray
+// needs the walk of the (wave-uniform) mesh publish the mesh-local ray in LDS, and the wave walks them 16 at a time
+// (quad::mesh_closest, unchanged: quad g takes the g-th waiting ray), the results going back to the owners' lanes.  Rays that
+// do not need a walk (missed the mesh's ball, answered by an analytic shape, no shadow query at all) take no quad's place.
+// Rays per wave: 64 when the list is long enough to fill the GPU that way, 32 / 16 for shorter lists (a wave's walks are
+// serial: a short list spread over few waves would only lengthen the level's chain).
+namespace coop {
+static const uint32_t kRecWords = 13;  // lo, ld (12 words) + t_stop: an odd stride, so 64 lanes' word k fall in 64 different banks
+__host__ __device__ __forceinline__ uint32_t wave_bytes(uint32_t stack_cap) {  // 16 stacks, 64 records, 16 source lanes
+    return (16u * (stack_cap + 1u) * 8u + 64u * kRecWords * 4u + 16u * 4u + 15u) & ~15u;
+}
+struct Lds {
+    uint2 *stack;     // this lane's quad's stack
+    uint32_t *rec;    // the wave's records
+    uint32_t *order;  // lanes of the rays the quads walk in this sub-round
+    uint32_t cap;
+};
+__device__ __forceinline__ void lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ uint32_t lo32(double v) { return (uint32_t)(unsigned long long)__double_as_longlong(v); }
+__device__ __forceinline__ uint32_t hi32(double v) { return (uint32_t)((unsigned long long)__double_as_longlong(v) >> 32); }
+__device__ __forceinline__ double mkd(uint32_t lo, uint32_t hi) { return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo)); }
+
+// quad::mesh_closest of mesh m for every lane that `want`s it (its ray in the mesh's frame: lo, ld), 16 rays at a time
+template <bool COUNT>
+__device__ __forceinline__ void walk(const SceneView &sv, const rthip_mesh &m, V3 lo, V3 ld, float t_stop, bool want, const Lds &L,
+                                     uint32_t lane, TriBest &out, KdCounters &cnt, uint32_t &max_walk_nodes) {
+    out.hit = false;
+    out.tie = false;
+    out.ext = 0.0;
+    out.d = DBL_MAX;
+    out.tri = 0xffffffffu;
+    out.ref = 0xffffffffu;
+    unsigned long long todo = __ballot(want);
+    if (!todo) return;
+    const uint32_t q = lane & 3u, g = lane >> 2;
+    if (want) {
+        uint32_t *r = L.rec + lane * kRecWords;
+        r[0] = lo32(lo.x); r[1] = hi32(lo.x); r[2] = lo32(lo.y); r[3] = hi32(lo.y); r[4] = lo32(lo.z); r[5] = hi32(lo.z);
+        r[6] = lo32(ld.x); r[7] = hi32(ld.x); r[8] = lo32(ld.y); r[9] = hi32(ld.y); r[10] = lo32(ld.z); r[11] = hi32(ld.z);
+        r[12] = __float_as_uint(t_stop);
+    }
+    quad::Stack qs;
+    qs.e = L.stack;
+    qs.cap = L.cap;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    while (todo) {  // (wave-uniform)
+        const uint32_t rank = (uint32_t)__popcll(todo & below);
+        const bool mine = ((todo >> lane) & 1ull) && rank < 16u;
+        if (mine) L.order[rank] = lane;
+        const uint32_t waiting = (uint32_t)__popcll(todo);
+        const bool act = g < (waiting < 16u ? waiting : 16u);
+        lds_fence();
+        const uint32_t *r = L.rec + (act ? L.order[g] : lane) * kRecWords;
+        const V3 o = mk(mkd(r[0], r[1]), mkd(r[2], r[3]), mkd(r[4], r[5]));
+        const V3 d = mk(mkd(r[6], r[7]), mkd(r[8], r[9]), mkd(r[10], r[11]));
+        const float ts = __uint_as_float(r[12]);
+        TriBest tb;
+        tb.hit = false;
+        tb.tie = false;
+        tb.d = DBL_MAX;
+        tb.tri = 0xffffffffu;
+        if (act) {
+            const uint32_t before = cnt.nodes;
+            quad::mesh_closest<COUNT>(sv, m, o, d, qs, q, ts, tb, cnt);
+            if (COUNT && cnt.nodes - before > max_walk_nodes) max_walk_nodes = cnt.nodes - before;
+        }
+        // the quads' results -> the owners' lanes (rank r was walked by quad r: lanes 4 r .. 4 r + 3 hold it)
+        const int from = (int)((rank & 15u) << 2);
+        const uint32_t rdlo = (uint32_t)__shfl((int)lo32(tb.d), from, 64), rdhi = (uint32_t)__shfl((int)hi32(tb.d), from, 64);
+        const uint32_t rtri = (uint32_t)__shfl((int)tb.tri, from, 64);
+        const uint32_t rfl = (uint32_t)__shfl((int)((tb.hit ? 1u : 0u) | (tb.tie ? 2u : 0u)), from, 64);
+        if (mine) {
+            out.d = mkd(rdlo, rdhi);
+            out.tri = rtri;
+            out.ref = rtri;
+            out.hit = (rfl & 1u) != 0u;
+            out.tie = (rfl & 2u) != 0u;
+        }
+        todo &= ~__ballot(mine);
+    }
+}
+
+// the mesh part of Scene::CastRay (Scene.cpp:163-237) for the lane's ray; quad::cast_ray's second loop, one ray per lane.
+// The ray is not passed by value: `ray(o, d)` fetches it where it is needed (closest query: the level's ray record in global
+// memory; shadow query: the hit point + the light's direction), and the lane's own mesh-local ray is read back from its LDS
+// record after the walk - nothing of it stays in registers across a walk, whose loop needs them all (5 waves per SIMD).
+template <bool COUNT, class RAY>
+__device__ __forceinline__ void cast_meshes(const SceneView &sv, const RAY &ray, bool any_hit, bool active, double &bd, uint32_t &bs,
+                                            int32_t &best_tri, bool &redo, const Lds &L, uint32_t lane, KdCounters &cnt,
+                                            uint32_t &max_walk_nodes) {
+    for (uint32_t s = 0; s < sv.n_shapes; s++) {
+        const rt_uniform_shape *sh = rt_uniform_cast(sv.shapes) + s;
+        if (sh->type != RTHIP_SHAPE_MESH) continue;
+        bool want = active && !redo && !(any_hit && bs != 0xffffffffu);
+        if (COUNT && want) cnt.shapes++;
+        const rthip_mesh m = rt_load_mesh(sv.meshes + sh->mesh);
+        TriBest tb;
+        {
+            V3 o, d;
+            ray(o, d);
+            if (want && ball_missed(sh->bound_c[0], sh->bound_c[1], sh->bound_c[2], sh->bound_r2, o, d)) want = false;
+            if (!__ballot(want)) continue;  // (wave-uniform: nobody is near this mesh)
+            if (COUNT && want) cnt.shapes_full++;
+            double inv[12];
+#pragma unroll
+            for (int k = 0; k < 12; k++) inv[k] = sh->inv[k];
+            const V3 lo = xform(inv, o, 1.0);
+            const V3 ld = normalized(xform(inv, d, 0.0));
+            if (want && kd_degenerate_ray(sv, m, lo, ld)) {
+                redo = true;
+                want = false;
+            }
+            float t_stop = 3.0e38f;
+            if (any_hit) {
+                double fwd[12];
+#pragma unroll
+                for (int k = 0; k < 12; k++) fwd[k] = sh->fwd[k];
+                t_stop = anyhit_t_stop(fwd, sh->rt_lin, sh->rt_t, o, ld);
+            }
+            walk<COUNT>(sv, m, lo, ld, t_stop, want, L, lane, tb, cnt, max_walk_nodes);
+        }
+        lds_fence();  // (also: nothing computed before the walk is reused below - it is fetched again)
+        if (!want || !tb.hit) continue;
+        if (tb.tie && !any_hit) {  // (a shadow query only consumes the distance)
+            redo = true;
+            continue;
+        }
+        const uint32_t *r = L.rec + lane * kRecWords;  // this lane's own record: its mesh-local ray
+        const V3 lo = mk(mkd(r[0], r[1]), mkd(r[2], r[3]), mkd(r[4], r[5]));
+        const V3 ld = mk(mkd(r[6], r[7]), mkd(r[8], r[9]), mkd(r[10], r[11]));
+        V3 p;
+        double u, v, ww;
+        tri_point(sv.tris[m.tri_base + tb.tri], lo, ld, p, u, v, ww);
+        double fwd[12];
+#pragma unroll
+        for (int k = 0; k < 12; k++) fwd[k] = sh->fwd[k];
+        const V3 worldPoint = xform(fwd, p, 1.0);
+        V3 o, d;
+        ray(o, d);
+        const double distance = sqlen(sub(o, worldPoint));
+        if (!(distance >= DBL_EPSILON)) continue;
+        if (distance < bd || (distance == bd && s < bs)) {
+            bd = distance;
+            bs = s;
+            best_tri = (int32_t)tb.tri;
+        }
+    }
+}
+
+// the analytic shapes of a shadow query, one ray per lane (quad::cast_ray's first loop; only .Hit is consumed, so the
+// first accepted shape ends the lane's search)
+template <bool COUNT>
+__device__ __forceinline__ void cast_analytic_any(const SceneView &sv, V3 o, V3 d, bool active, double &bd, uint32_t &bs, KdCounters &cnt) {
+    for (uint32_t s = 0; s < sv.n_shapes; s++) {
+        const rt_uniform_shape *sh = rt_uniform_cast(sv.shapes) + s;
+        const int32_t type = sh->type;
+        if (type == RTHIP_SHAPE_MESH) continue;
+        if (!active || bs != 0xffffffffu) continue;
+        if (COUNT) cnt.shapes++;
+        if (type == RTHIP_SHAPE_SPHERE && ball_missed(sh->bound_c[0], sh->bound_c[1], sh->bound_c[2], sh->bound_r2, o, d)) continue;
+        if (COUNT) cnt.shapes_full++;
+        double inv[12];
+#pragma unroll
+        for (int k = 0; k < 12; k++) inv[k] = sh->inv[k];
+        const V3 lo = xform(inv, o, 1.0);
+        const V3 ld = normalized(xform(inv, d, 0.0));
+        V3 p;
+        const bool hit = type == RTHIP_SHAPE_SPHERE ? sphere_intersect(lo, ld, p)
+                                                    : plane_intersect(mk(sh->plane_n[0], sh->plane_n[1], sh->plane_n[2]), lo, ld, p);
+        if (!hit) continue;
+        double fwd[12];
+#pragma unroll
+        for (int k = 0; k < 12; k++) fwd[k] = sh->fwd[k];
+        const V3 worldPoint = xform(fwd, p, 1.0);
+        const double distance = sqlen(sub(o, worldPoint));
+        if (!(distance >= DBL_EPSILON)) continue;
+        bd = distance;
+        bs = s;
+    }
+}
+}  // namespace coop
+
+// Lists shorter than thr32 are k_trace_quad's (launched just before: one of the two kernels returns at once).  Both paths in ONE
+// kernel had the quad code's walk loops spill (their registers are allocated together): a lone frame 2.6 % slower.
+template <bool COUNT, int OCC = RT_QUAD_OCC>
+__global__ __launch_bounds__(kBlock, OCC) void k_trace_coop(SceneView sv, FrameParams fp, Work w, uint32_t level, uint32_t stack_cap,
+                                                            uint32_t thr32, uint32_t thr64) {
+    const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
+    const uint32_t n = min(w.N, w.hard_count[0]);
+    if (n < thr32) return;
+    char *wave_lds = reinterpret_cast<char *>(lds_dyn) + wid * coop::wave_bytes(stack_cap);
+    coop::Lds L;
+    L.cap = stack_cap;
+    L.stack = reinterpret_cast<uint2 *>(wave_lds) + (lane >> 2) * (stack_cap + 1u);
+    L.rec = reinterpret_cast<uint32_t *>(wave_lds + 16u * (stack_cap + 1u) * 8u);
+    L.order = L.rec + 64u * coop::kRecWords;
+    const uint32_t n_shadow = fp.renderer == RTHIP_RENDER_RAYTRACER ? sv.n_lights : 0u;  // DebugRaycaster: closest hit only
+    KdCounters kc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t max_walk_nodes = 0;
+    const long long t_start = COUNT ? clock64() : 0;
+    stage_store(w, w.stage_base + STAGES_PER_LEVEL * level + STAGE_WALK);
+    // Rays per wave: 64 when the list is long enough to fill the GPU that way, 32 for a shorter one (a wave's rounds are serial:
+    // a short list dealt 64 at a time would leave SIMDs idle while a few waves walk their four rounds).  Waves stride over the
+    // list.  (Claiming the rays with one atomic per wave on a counter cost more than the walks - ~15 ns per claim, serialised -,
+    // and dealing the list in the order the waves start, 64 m consecutive rays each and 16 at a time for the last ones, was
+    // slower than the stride on long lists: profiles/r03_coop_walk.txt.)
+    const uint32_t R = n >= thr64 ? 64u : 32u;
+    const uint32_t gw = blockIdx.x * (kBlock / 64u) + wid, n_waves = gridDim.x * (kBlock / 64u);
+    uint32_t it = 0;
+    for (uint32_t base = gw * R; base < n; base += n_waves * R) {  // (wave-uniform)
+        if ((++it & (kIrqEvery - 1u)) == 0u && __builtin_amdgcn_readfirstlane((int)irq_load(w))) break;  // Interrupt(): see k_trace
+        const uint32_t j = base + lane;
+        const bool live = lane < R && j < n;
+        const uint32_t i = live ? w.hard[j] : 0u;
+        double bd = DBL_MAX;
+        uint32_t bs = 0xffffffffu;
+        if (live) {
+            const PendRec known = w.pend[j];  // the closest hit over the analytic shapes (k_trace_easy)
+            bd = known.bd;
+            bs = known.bs;
+        }
+        // the level's ray of this lane, fetched from its record wherever it is needed (level 0 too: k_trace_easy has stored the
+        // primary rays it listed); the asm keeps the compiler from holding the first fetch in registers instead
+        const RayRec *my_ray = &ray_at(w, level, i);
+        auto level_ray = [&](V3 &o, V3 &d) {
+            asm volatile("" ::: "memory");
+            o = mk(0, 0, 0);
+            d = mk(0, 0, 1);
+            if (live) {
+                const RayRec r = *my_ray;
+                o = mk(r.ox, r.oy, r.oz);
+                d = mk(r.dx, r.dy, r.dz);
+            }
+        };
+        bool redo = false;
+        int32_t hit_shape = -1, hit_tri = -1;
+        uint32_t shadow_mask = 0u;
+        V3 point = mk(0, 0, 0);
+        {   // the closest hit
+            int32_t tri = -1;
+            coop::cast_meshes<COUNT>(sv, level_ray, false, live, bd, bs, tri, redo, L, lane, kc, max_walk_nodes);
+            if (live && !redo && bs != 0xffffffffu) {
+                Hit c;
+                V3 o, d;
+                level_ray(o, d);
+                hit_details(sv, o, d, (int32_t)bs, tri, c, COUNT ? &kc : nullptr);
+                hit_shape = (int32_t)bs;
+                hit_tri = tri;
+                HitRec rec;
+                rec.shape = hit_shape;
+                rec.tri = tri;
+                rec.shadow_mask = 0;
+                rec.local = c.local;
+                rec.normal = c.normal;
+                store_hit(w, i, rec);  // (the shadow mask is patched in below)
+                point = c.point;       // every shadow ray starts there
+            }
+        }
+        for (uint32_t l = 0; l < n_shadow; l++) {
+            const rt_uniform_light *light = rt_uniform_cast(sv.lights) + l;
+            const int32_t ltype = light->type;
+            if (!light->enabled || ltype == RTHIP_LIGHT_AMBIENT) continue;  // Raytracer.cpp:213, 234-237
+            const bool active = live && !redo && hit_shape >= 0;
+            auto shadow_ray = [&](V3 &o, V3 &d) {  // (a directional light's direction is wave-uniform: scalar registers)
+                o = point;
+                if (ltype == RTHIP_LIGHT_DIRECTIONAL)
+                    d = mk(light->direction[0], light->direction[1], light->direction[2]);
+                else
+                    d = normalized(sub(mk(light->position[0], light->position[1], light->position[2]), point));
+            };
+            double sd = DBL_MAX;
+            uint32_t ss = 0xffffffffu;
+            int32_t tri = -1;
+            {
+                V3 ro, rd;
+                shadow_ray(ro, rd);
+                coop::cast_analytic_any<COUNT>(sv, ro, rd, active, sd, ss, kc);
+            }
+            coop::cast_meshes<COUNT>(sv, shadow_ray, true, active, sd, ss, tri, redo, L, lane, kc, max_walk_nodes);
+            if (ss != 0xffffffffu) shadow_mask |= 1u << l;
+        }
+        if (!live) continue;
+        if (redo) {  // -> redo list; its hit slot says so, so that k_shade's pass over the hard list leaves the ray to its redo pass
+            const uint32_t slot = atomicAdd(&w.redo_count[0], 1u);
+            if (slot < w.N) w.redo[slot] = i;
+            w.hit[i].shape = kShapeRedo;
+            continue;
+        }
+        if (hit_shape < 0) {  // a miss: the whole record
+            HitRec h;
+            h.shape = -1;
+            h.tri = -1;
+            h.shadow_mask = 0;
+            h.local = h.normal = mk(0, 0, 0);
+            store_hit(w, i, h);
+        } else if (shadow_mask) {
+            w.hit[i].mask = shadow_mask;  // the record itself was stored after the closest query
+        }
+        if (level == 0 && w.id_shape && i / fp.n_pix_slots == (fp.aa ? 4u : 0u)) {
+            const uint32_t pix_slot = fp.aa ? i - rtc::fast_div(i, fp.d_pix_slots) * fp.n_pix_slots : i;
+            w.id_shape[pix_slot] = hit_shape;
+            w.id_tri[pix_slot] = hit_tri;
+        }
+    }
+    if (COUNT) trace_counters_flush(fp, w, kc, max_walk_nodes, t_start);
+}
 // Stage 2 of a level for the rays that went through a hit record: LIST = true, the hard rays of the BVH
 // path (traced by k_trace_quad / the redo kernel); LIST = false, every ray of the level (accel = 1, where
 // k_trace does all the tracing).  The Perlin tables (256 B each) are staged in LDS: their chained lookups
@@ -1468,6 +1787,10 @@ struct rthip_ctx {
     uint32_t bs_stride = 0, bs_levels = 0;
     uint32_t n_tables = 0;
     bool has_meshes = false;
+    bool walk_coop = false;  // hard rays through k_trace_coop (per-ray work one ray per lane) instead of k_trace_quad: trees that stay in L2
+    int coop_forced = -1;    // RTHIP_QUAD_COOP
+    size_t coop_max_bytes = (size_t)8 << 20;
+    uint32_t coop_thr32 = 300000u, coop_thr64 = 600000u;
     int mesh_without_bvh = -1;  // first mesh that has triangles but no BVH (a caller that supplied only the kd-tree), -1 = none
     std::atomic<int> interrupt{0};
     std::atomic<float> progress{0.f};
@@ -1573,6 +1896,16 @@ int rthip_create(int device, rthip_ctx **out) {
     if (env && atoll(env) > 0) { c->chunk_rays = (size_t)atoll(env); c->chunk_rays_forced = true; }
     env = getenv("RTHIP_PROFILE_LAUNCHES");
     c->profile_launches = env && atoi(env) != 0;
+    // the walk kernel (k_trace_coop / k_trace_quad; the default follows the scene, see upload_scene): 1 / 0 force it, and the list
+    // lengths from which a wave of k_trace_coop takes 32 / 64 rays (read per context: tests and A/B runs hold several)
+    env = getenv("RTHIP_QUAD_COOP");
+    c->coop_forced = env ? (atoi(env) != 0 ? 1 : 0) : -1;
+    env = getenv("RTHIP_COOP_MAX_TREE_MB");
+    c->coop_max_bytes = (size_t)(env && atoi(env) > 0 ? atoi(env) : 8) << 20;
+    env = getenv("RTHIP_COOP_T32");
+    c->coop_thr32 = env && atoi(env) > 0 ? (uint32_t)atoi(env) : 300000u;
+    env = getenv("RTHIP_COOP_T64");
+    c->coop_thr64 = env && atoi(env) > 0 ? (uint32_t)atoi(env) : 600000u;
     memset(&c->sv, 0, sizeof c->sv);
     *out = c;
     return 0;
@@ -2038,6 +2371,11 @@ static int upload_scene_impl(rthip_ctx *c, const rthip_scene_desc *s, bool keep_
     c->mesh_without_bvh = -1;
     for (uint32_t i = 0; i < s->n_meshes; i++)
         if (c->mesh_table[i].tri_count && !c->mesh_table[i].bvh_node_count && c->mesh_without_bvh < 0) c->mesh_without_bvh = (int)i;
+    {   // which walk kernel serves this scene (see k_trace_coop): the footprint of what the walks read
+        size_t bytes = 0;
+        for (const rthip_mesh &m : c->mesh_table) bytes += (size_t)m.bvh_node_count * sizeof(rthip_bvhnode) + (size_t)m.tri_count * (sizeof(rthip_tri) + 4u);
+        c->walk_coop = c->coop_forced >= 0 ? c->coop_forced == 1 : bytes <= c->coop_max_bytes;
+    }
     v.bg = s->background;
     c->stack_cap_kd = max_depth + 2;
     c->bvh_depth = max_bvh_depth;
@@ -2221,6 +2559,22 @@ static int render_frame(rthip_ctx *c, const rthip_camera *cam, uint32_t n_frames
         HIP_TRY(hipFuncSetAttribute((const void *)k_trace_quad<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_quad));
         HIP_TRY(hipFuncSetAttribute((const void *)k_trace_quad<false, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_quad));
     }
+    // the walk kernel with one ray per lane outside the walks (k_trace_coop) when the scene's trees are small (upload_scene)
+    const bool quad_coop = c->walk_coop && !quad_occ6;
+    static const uint32_t max_grid_coop = [] { const char *e = getenv("RTHIP_GRID_COOP"); return e && atoi(e) > 0 ? (uint32_t)atoi(e) : kMaxGridCoop; }();
+    const uint32_t coop_thr32 = c->coop_thr32, coop_thr64 = c->coop_thr64;
+    const size_t lds_coop = (size_t)(kBlock / 64u) * coop::wave_bytes(quad_cap);
+    if (quad_coop && lds_coop > 48 * 1024) {
+        HIP_TRY(hipFuncSetAttribute((const void *)k_trace_coop<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_coop));
+        HIP_TRY(hipFuncSetAttribute((const void *)k_trace_coop<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_coop));
+    }
+    static const bool debug_occ = [] { const char *e = getenv("RTHIP_DEBUG_OCC"); return e && atoi(e) != 0; }();
+    if (debug_occ) {  // resident workgroups per CU of the two walk kernels at this scene's LDS sizes (tuning aid)
+        int bq = 0, bc = 0;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&bq, (const void *)k_trace_quad<false>, (int)kBlock, lds_quad);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&bc, (const void *)k_trace_coop<false>, (int)kBlock, lds_coop);
+        fprintf(stderr, "rthip: quad_cap %u: k_trace_quad %zu B LDS -> %d workgroups / CU, k_trace_coop %zu B -> %d\n", quad_cap, lds_quad, bq, lds_coop, bc);
+    }
     const size_t lds_tables = (size_t)c->n_tables * 256;
 
     // ---- the call's cameras -> this call's slot of the page-locked ring (k_begin fetches them; see kCamSlots)
@@ -2316,12 +2670,20 @@ static int render_frame(rthip_ctx *c, const rthip_camera *cam, uint32_t n_frames
                 if (c->has_meshes) {  // the rays that need a mesh walk (count on the device: the grid is an upper bound, strided)
                     uint32_t qgrid = (fp.N0 + quad::kRaysPerBlock - 1) / quad::kRaysPerBlock;
                     if (qgrid > max_grid_quad) qgrid = max_grid_quad;
+                    // short lists through k_trace_quad, long ones of a scene with small trees through k_trace_coop: the length is on
+                    // the device, so both are launched and one of them returns at once
+                    const uint32_t n_coop = quad_coop ? coop_thr32 : 0xffffffffu;
                     if (c->count_kd)
-                        hipLaunchKernelGGL((k_trace_quad<true>), dim3(qgrid), dim3(kBlock), lds_quad, c->stream, c->sv, fp, w, level, quad_cap);
+                        hipLaunchKernelGGL((k_trace_quad<true>), dim3(qgrid), dim3(kBlock), lds_quad, c->stream, c->sv, fp, w, level, quad_cap, n_coop);
                     else if (quad_occ6)
-                        hipLaunchKernelGGL((k_trace_quad<false, 6>), dim3(qgrid), dim3(kBlock), lds_quad, c->stream, c->sv, fp, w, level, quad_cap);
+                        hipLaunchKernelGGL((k_trace_quad<false, 6>), dim3(qgrid), dim3(kBlock), lds_quad, c->stream, c->sv, fp, w, level, quad_cap, n_coop);
                     else
-                        hipLaunchKernelGGL((k_trace_quad<false>), dim3(qgrid), dim3(kBlock), lds_quad, c->stream, c->sv, fp, w, level, quad_cap);
+                        hipLaunchKernelGGL((k_trace_quad<false>), dim3(qgrid), dim3(kBlock), lds_quad, c->stream, c->sv, fp, w, level, quad_cap, n_coop);
+                    const uint32_t cgrid = qgrid < max_grid_coop ? qgrid : max_grid_coop;
+                    if (quad_coop && c->count_kd)
+                        hipLaunchKernelGGL((k_trace_coop<true>), dim3(cgrid), dim3(kBlock), lds_coop, c->stream, c->sv, fp, w, level, quad_cap, coop_thr32, coop_thr64);
+                    else if (quad_coop)
+                        hipLaunchKernelGGL((k_trace_coop<false>), dim3(cgrid), dim3(kBlock), lds_coop, c->stream, c->sv, fp, w, level, quad_cap, coop_thr32, coop_thr64);
                 }
                 if (profile) HIP_TRY(hipEventRecord(eb, c->stream));
                 // (the redo list - rays lying exactly in a kd split plane, exact distance ties - is re-traced inside k_shade)
@@ -2784,6 +3146,7 @@ int rthip_probe_kd(rthip_ctx *c, uint32_t mesh, rthip_mesh *out_mesh, rthip_kdno
 int rthip_get_upload_info(rthip_ctx *c, rthip_upload_info *out) {
     if (!c || !out) return fail(RTHIP_E_INVALID, "null argument");
     *out = c->upload_info;
+    out->walk_coop = c->walk_coop ? 1u : 0u;
     return 0;
 }
 int rthip_probe_arith(rthip_ctx *c, int32_t op, uint32_t n, const double *a, const double *b, double *out) {

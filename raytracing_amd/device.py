@@ -79,7 +79,7 @@ class SceneDesc(C.Structure):  # rthip_scene_desc (tests build variants of a fla
 
 
 class UploadInfo(C.Structure):  # rthip_upload_info
-    _fields_ = [("kd_meshes", C.c_uint32), ("kd_nodes", C.c_uint32), ("kd_levels", C.c_uint32), ("pad", C.c_uint32), ("kd_refs", C.c_uint64),
+    _fields_ = [("kd_meshes", C.c_uint32), ("kd_nodes", C.c_uint32), ("kd_levels", C.c_uint32), ("walk_coop", C.c_uint32), ("kd_refs", C.c_uint64),
                 ("kd_device_ms", C.c_float), ("bvh_meshes", C.c_uint32), ("bvh_nodes", C.c_uint32), ("upload_ms", C.c_float)]
 
 

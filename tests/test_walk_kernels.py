@@ -1,0 +1,143 @@
+"""The two kernels that trace the rays which need a mesh walk (rthip.hip): k_trace_quad - everything of a ray in the four lanes
+of its quad, 16 rays per wave - and k_trace_coop - per-ray work one ray per lane, up to 64 rays per wave, the walks 16 at a time.
+Which one a context uses follows its scene (small trees: k_trace_coop; RTHIP_QUAD_COOP forces it), and inside k_trace_coop the
+length of the level's list picks 64 / 32 rays per wave or the quad code (RTHIP_COOP_T64 / RTHIP_COOP_T32).  The choice must
+never show in a frame: every mode here gives the oracle's pixels, ids and ray counts (Scene.cpp:163-237, Raytracer.cpp:187-315)."""
+import numpy as np
+import pytest
+
+from raytracing_amd import device, host, scenes
+
+import edge_scenes
+import fuzz_scenes
+from test_ties import tie_scene
+
+pytestmark = pytest.mark.gpu
+
+BIG = str(2**31 - 1)
+MODES = {
+    "quad": {"RTHIP_QUAD_COOP": "0"},
+    "coop64": {"RTHIP_QUAD_COOP": "1", "RTHIP_COOP_T32": "1", "RTHIP_COOP_T64": "1"},   # every list 64 rays per wave
+    "coop32": {"RTHIP_QUAD_COOP": "1", "RTHIP_COOP_T32": "1", "RTHIP_COOP_T64": BIG},   # every list 32 rays per wave
+    "coop_short": {"RTHIP_QUAD_COOP": "1", "RTHIP_COOP_T32": BIG, "RTHIP_COOP_T64": BIG},  # k_trace_coop, every list too short: its fallback to the quad code
+    "default": {},
+}
+
+
+def _render(monkeypatch, mode, sd, w, h, **kw):
+    for k in ("RTHIP_QUAD_COOP", "RTHIP_COOP_T32", "RTHIP_COOP_T64"):
+        monkeypatch.delenv(k, raising=False)
+    for k, v in MODES[mode].items():
+        monkeypatch.setenv(k, v)   # (read when the context is created: rthip_create)
+    return host.HostScene(sd).render(w, h, ids=True, **kw)
+
+
+def _same(got, ref, what):
+    assert np.array_equal(got["shape"], ref["shape"]), f"{what}: {(got['shape'] != ref['shape']).sum()} shape ids differ"
+    assert np.array_equal(got["tri"], ref["tri"]), f"{what}: {(got['tri'] != ref['tri']).sum()} triangle ids differ"
+    assert np.array_equal(got["pixels"], ref["pixels"]), f"{what}: {(got['pixels'] != ref['pixels']).sum()} pixels differ"
+    assert got["rays"] == ref["rays"], f"{what}: {got['rays']} rays, the reference traces {ref['rays']}"
+
+
+@pytest.mark.parametrize("mode", list(MODES))
+def test_bunny_close_up_and_multi_mesh_scene(monkeypatch, oracle_lib, mode):
+    """one mesh under a sun (closest + one shadow walk per ray), and five rotated / scaled meshes + 16 spheres + plane at depth 6
+    and with SSAA (several meshes per query, analytic shadow casters, rays that need no walk at all)"""
+    sd = scenes.config(3, cam_z=2.4)[0]
+    ref = sd.build(oracle_lib).render(224, 126, ids=True, threads=8, max_recursion=3)
+    _same(_render(monkeypatch, mode, sd, 224, 126, max_recursion=3), ref, f"{mode} bunny")
+    sd = scenes.config(5, cells=24)[0]
+    for kw in (dict(max_recursion=6), dict(max_recursion=2, aa=1)):
+        ref = sd.build(oracle_lib).render(160, 90, ids=True, threads=8, **kw)
+        _same(_render(monkeypatch, mode, sd, 160, 90, **kw), ref, f"{mode} multi-mesh {kw}")
+
+
+@pytest.mark.parametrize("mode", ["coop64", "coop32", "coop_short"])
+def test_random_scenes_edge_scenes_ties_and_degenerate_rays(monkeypatch, oracle_lib, mode):
+    """what only the redo list settles (exact ties, rays in a kd plane) and the generator's scenes: point / spot lights (per-ray
+    shadow directions), nested transforms, empty meshes, a single triangle, recursion 16"""
+    for seed in fuzz_scenes.FUZZ_SEEDS[:12]:
+        sd = fuzz_scenes.random_scene(seed)
+        kw = dict(max_recursion=4, aa=1 if seed % 5 == 0 else 0)
+        ref = sd.build(oracle_lib).render(96, 64, ids=True, threads=8, **kw)
+        _same(_render(monkeypatch, mode, sd, 96, 64, **kw), ref, f"{mode} fuzz {seed}")
+    for name, (mk, runs) in edge_scenes.EDGE_CASES.items():
+        w, h, kw = runs[0]
+        sd = mk()
+        ref = sd.build(oracle_lib).render(w, h, ids=True, threads=4, **kw)
+        _same(_render(monkeypatch, mode, sd, w, h, **kw), ref, f"{mode} {name}")
+    sd, _ = tie_scene(2)
+    ref = sd.build(oracle_lib).render(64, 48, ids=True, threads=4, max_recursion=2)
+    _same(_render(monkeypatch, mode, sd, 64, 48, max_recursion=2), ref, f"{mode} ties")
+    sd = scenes.SceneDesc("grid mesh symmetric about x = 0, camera on the plane x = 0")
+    m = sd.uniform_material(0x88aa66, 0.8)
+    v, n = scenes.heightfield_mesh(cells=32, seed=5, extent=4.0)
+    sd.mesh(m, v, n, scenes.NORMAL_VERTEX)
+    sd.directional_light(0xffffff, 1, 2, 1)
+    sd.color_background(0x102030)
+    sd.look_at((0, 5, 9), (0, 0, 0))
+    ref = sd.build(oracle_lib).render(128, 96, ids=True, threads=8, max_recursion=2)
+    _same(_render(monkeypatch, mode, sd, 128, 96, max_recursion=2), ref, f"{mode} kd-plane rays")
+
+
+def test_long_lists_of_a_batch_take_the_wide_path_and_equal_the_single_frames(monkeypatch):
+    """the default thresholds at work: a call of 6 frames of the benchmark scene at 1080p lists > 600 000 rays per level for the
+    walk (64 rays per wave), a lone frame of it < 300 000 (the quad code): every frame of the call equals its lone render"""
+    import torch
+    for k in ("RTHIP_QUAD_COOP", "RTHIP_COOP_T32", "RTHIP_COOP_T64"):
+        monkeypatch.delenv(k, raising=False)
+    sd, kw = scenes.config(3)
+    w, h, mr = kw["width"], kw["height"], kw["max_recursion"]
+    hs = host.HostScene(sd)
+    ctx = device.Context(0)
+    try:
+        ctx.upload(hs.flatten())
+        prm = device.make_params(w, h, mr)
+        cams = []
+        for k in range(6):
+            cam = hs.camera(w, h)
+            cam.position[0] = -0.5 + 0.2 * k
+            cams.append(cam)
+        one = torch.zeros(w * h, dtype=torch.int32, device="cuda")
+        singles, rays, hard = [], 0, []
+        for cam in cams:
+            ctx.render_device(cam, prm, one.data_ptr(), sync=True)
+            singles.append(one.clone())
+            st = ctx.stats()
+            rays += st.rays_primary + st.rays_shadow + st.rays_reflect
+            hard.append(st.rays_hard)
+        assert max(hard) < 4 * 300000 and sum(hard) > 4 * 600000 * 0.5, hard   # (rays_hard sums the four levels)
+        buf = torch.zeros(len(cams) * w * h, dtype=torch.int32, device="cuda")
+        for rep in range(3):   # plain launches, the capture, a replay
+            buf.zero_()
+            ctx.render_batch_device(cams, prm, buf.data_ptr(), sync=True)
+            for k in range(len(cams)):
+                assert torch.equal(buf[k * w * h:(k + 1) * w * h], singles[k]), f"frame {k} of the call (rep {rep}) differs from its lone render"
+        st = ctx.stats()
+        assert st.rays_primary + st.rays_shadow + st.rays_reflect == rays
+    finally:
+        ctx.close()
+
+
+def test_counting_contexts_count_the_same_walks_in_both_kernels(monkeypatch):
+    """RTHIP_COUNTERS=1 (bench.py's flop accounting): BVH steps, triangle tests and walked rays do not depend on the kernel"""
+    import torch
+    sd = scenes.config(3, cam_z=2.4)[0]
+    hs = host.HostScene(sd)
+    w, h = 320, 180
+    got = {}
+    for mode in ("quad", "coop64"):
+        for k, v in MODES[mode].items():
+            monkeypatch.setenv(k, v)
+        monkeypatch.setenv("RTHIP_COUNTERS", "1")
+        ctx = device.Context(0)
+        monkeypatch.setenv("RTHIP_COUNTERS", "0")
+        try:
+            ctx.upload(hs.flatten())
+            fb = torch.zeros(w * h, dtype=torch.int32, device="cuda")
+            ctx.render_device(hs.camera(w, h), device.make_params(w, h, 3), fb.data_ptr(), sync=True)
+            st = ctx.stats()
+            got[mode] = (int(st.kd_nodes_visited), int(st.kd_tris_tested), int(st.rays_hard), int(fb.to(torch.int64).sum()))
+        finally:
+            ctx.close()
+    assert got["quad"] == got["coop64"] and got["quad"][0] > 100000, got
