@@ -191,6 +191,10 @@ struct Work {
     const uint32_t *irq_host;   // the request itself: a word in page-locked host memory that rthip_interrupt stores to
     uint32_t *stage;
     uint32_t stage_base;        // stage index of the current chunk's first kernel
+    // the lengths of this call's hard lists, level by level, for the host (page-locked memory): the next call of the same shape
+    // launches only the walk kernel such lists are for (render_frame: walk_mode); hist[0] = hist_tag says whose lengths they are
+    uint32_t *hist;
+    uint32_t hist_tag;
 };
 // Workgroup 0 of every kernel is the watcher: it reads the request word in host memory (a PCIe read, so only this one workgroup
 // does it, once per grid-stride iteration - its iterations are spread over the kernel's whole run) and raises the device-side
@@ -1662,6 +1666,11 @@ __global__ __launch_bounds__(kBlock) void k_resolve(FrameParams fp, Work w, uint
                                                     int32_t *out_tri) {
     uint32_t ps = blockIdx.x * kBlock + threadIdx.x;
     stage_store(w, w.stage_base + STAGES_PER_LEVEL * (fp.max_rec + 1u));
+    if (blockIdx.x == 0 && threadIdx.x <= fp.max_rec && w.hist) {
+        const uint32_t listed = w.counts[(size_t)(2 * (RTHIP_MAX_RECURSION + 3) + threadIdx.x) * kCounterStride];  // (the level's hard_count)
+        __hip_atomic_store(w.hist + 1 + threadIdx.x, listed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (threadIdx.x == 0) __hip_atomic_store(w.hist, w.hist_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     if (ps >= fp.n_pix_slots) return;
     if (irq_load(w)) return;  // Interrupt(): the chains are incomplete, the frame is abandoned (Raytracer.cpp:153)
     uint32_t x, y, frame, part_slot;
@@ -1881,7 +1890,7 @@ int rthip_create(int device, rthip_ctx **out) {
     static_assert(sizeof(((rthip_ctx *)nullptr)->cam_ev) / sizeof(hipEvent_t) == kCamSlots, "one event per camera slot");
     for (uint32_t k = 0; k < kCamSlots && e == hipSuccess; k++) e = hipEventCreateWithFlags(&c->cam_ev[k], hipEventDisableTiming);
     if (e == hipSuccess) e = hipHostMalloc((void **)&c->h_stage, 256, hipHostMallocMapped);
-    if (e == hipSuccess) c->h_stage[0] = c->h_stage[32] = 0;
+    if (e == hipSuccess) for (int k = 0; k < 64; k++) c->h_stage[k] = 0;  // (0: stage, 8..: the last call's list lengths, 32: interrupt request)
     if (e == hipSuccess) e = hipEventCreate(&c->ev0);
     if (e == hipSuccess) e = hipEventCreate(&c->ev1);
     if (e != hipSuccess) {
@@ -2533,6 +2542,8 @@ static int render_frame(rthip_ctx *c, const rthip_camera *cam, uint32_t n_frames
     w.irq = c->d_irq;
     w.irq_host = (const uint32_t *)(c->h_stage + 32);
     w.stage = (uint32_t *)c->h_stage;
+    w.hist = nullptr;
+    w.hist_tag = 0;
     w.stage_base = 0;
     const uint32_t stages_per_chunk = STAGES_PER_LEVEL * levels + 1;  // + k_resolve
     c->stages_total.store(((my_tiles + tiles_per_chunk - 1) / tiles_per_chunk) * stages_per_chunk);
@@ -2561,6 +2572,28 @@ static int render_frame(rthip_ctx *c, const rthip_camera *cam, uint32_t n_frames
     }
     // the walk kernel with one ray per lane outside the walks (k_trace_coop) when the scene's trees are small (upload_scene)
     const bool quad_coop = c->walk_coop && !quad_occ6;
+    // Which of the two walk kernels a level launches.  The length of its list is on the device, so a scene with small trees gets
+    // both and one returns at once (~2.5 us of a lone frame's chain per level) - unless the last call of this very shape (frames,
+    // size, depth, part) has reported its lists (k_resolve -> page-locked words) and the level's was clearly on one side of the
+    // threshold: then only that kernel is launched, with no threshold of its own.  A wrong guess costs speed, never a ray.
+    enum { WALK_BOTH = 0, WALK_QUAD = 1, WALK_COOP = 2 };
+    uint8_t walk_mode[RTHIP_MAX_RECURSION + 1];
+    for (uint32_t l = 0; l <= RTHIP_MAX_RECURSION; l++) walk_mode[l] = quad_coop ? WALK_BOTH : WALK_QUAD;
+    if (quad_coop && c->h_stage && !c->count_kd) {
+        uint32_t tag = 2166136261u;
+        auto mix = [&](const void *ptr, size_t nb) { for (size_t k = 0; k < nb; k++) tag = (tag ^ ((const unsigned char *)ptr)[k]) * 16777619u; };
+        mix(&n_frames, sizeof n_frames);
+        mix(p, sizeof *p);
+        mix(&c->scene_generation, sizeof c->scene_generation);
+        if (!tag) tag = 1;
+        w.hist = (uint32_t *)c->h_stage + 8;  // words 8 .. 8 + levels of the stage block (0: stage, 32: interrupt request)
+        w.hist_tag = tag;
+        if (__atomic_load_n(c->h_stage + 8, __ATOMIC_ACQUIRE) == tag)
+            for (uint32_t l = 0; l < levels; l++) {
+                const uint64_t listed = c->h_stage[9 + l];
+                walk_mode[l] = listed * 10u < (uint64_t)c->coop_thr32 * 7u ? WALK_QUAD : (listed * 10u > (uint64_t)c->coop_thr32 * 14u ? WALK_COOP : WALK_BOTH);
+            }
+    }
     static const uint32_t max_grid_coop = [] { const char *e = getenv("RTHIP_GRID_COOP"); return e && atoi(e) > 0 ? (uint32_t)atoi(e) : kMaxGridCoop; }();
     const uint32_t coop_thr32 = c->coop_thr32, coop_thr64 = c->coop_thr64;
     const size_t lds_coop = (size_t)(kBlock / 64u) * coop::wave_bytes(quad_cap);
@@ -2605,6 +2638,7 @@ static int render_frame(rthip_ctx *c, const rthip_camera *cam, uint32_t n_frames
         put(ptrs, sizeof ptrs);
         put(&c->scene_generation, sizeof c->scene_generation);
         put(&c->count_kd, sizeof c->count_kd);
+        put(walk_mode, sizeof walk_mode);
         for (const auto &g : c->graphs) {
             if (g.key != key) continue;
             if ((rc = stage_cams())) return rc;
@@ -2672,18 +2706,24 @@ static int render_frame(rthip_ctx *c, const rthip_camera *cam, uint32_t n_frames
                     if (qgrid > max_grid_quad) qgrid = max_grid_quad;
                     // short lists through k_trace_quad, long ones of a scene with small trees through k_trace_coop: the length is on
                     // the device, so both are launched and one of them returns at once
-                    const uint32_t n_coop = quad_coop ? coop_thr32 : 0xffffffffu;
-                    if (c->count_kd)
-                        hipLaunchKernelGGL((k_trace_quad<true>), dim3(qgrid), dim3(kBlock), lds_quad, c->stream, c->sv, fp, w, level, quad_cap, n_coop);
-                    else if (quad_occ6)
-                        hipLaunchKernelGGL((k_trace_quad<false, 6>), dim3(qgrid), dim3(kBlock), lds_quad, c->stream, c->sv, fp, w, level, quad_cap, n_coop);
-                    else
-                        hipLaunchKernelGGL((k_trace_quad<false>), dim3(qgrid), dim3(kBlock), lds_quad, c->stream, c->sv, fp, w, level, quad_cap, n_coop);
-                    const uint32_t cgrid = qgrid < max_grid_coop ? qgrid : max_grid_coop;
-                    if (quad_coop && c->count_kd)
-                        hipLaunchKernelGGL((k_trace_coop<true>), dim3(cgrid), dim3(kBlock), lds_coop, c->stream, c->sv, fp, w, level, quad_cap, coop_thr32, coop_thr64);
-                    else if (quad_coop)
-                        hipLaunchKernelGGL((k_trace_coop<false>), dim3(cgrid), dim3(kBlock), lds_coop, c->stream, c->sv, fp, w, level, quad_cap, coop_thr32, coop_thr64);
+                    const uint32_t mode = walk_mode[level];
+                    const uint32_t n_coop = mode == WALK_BOTH ? coop_thr32 : 0xffffffffu;  // lists from this length on are k_trace_coop's
+                    const uint32_t thr32 = mode == WALK_BOTH ? coop_thr32 : 0u;
+                    if (mode != WALK_COOP) {
+                        if (c->count_kd)
+                            hipLaunchKernelGGL((k_trace_quad<true>), dim3(qgrid), dim3(kBlock), lds_quad, c->stream, c->sv, fp, w, level, quad_cap, n_coop);
+                        else if (quad_occ6)
+                            hipLaunchKernelGGL((k_trace_quad<false, 6>), dim3(qgrid), dim3(kBlock), lds_quad, c->stream, c->sv, fp, w, level, quad_cap, n_coop);
+                        else
+                            hipLaunchKernelGGL((k_trace_quad<false>), dim3(qgrid), dim3(kBlock), lds_quad, c->stream, c->sv, fp, w, level, quad_cap, n_coop);
+                    }
+                    if (mode != WALK_QUAD) {
+                        const uint32_t cgrid = qgrid < max_grid_coop ? qgrid : max_grid_coop;
+                        if (c->count_kd)
+                            hipLaunchKernelGGL((k_trace_coop<true>), dim3(cgrid), dim3(kBlock), lds_coop, c->stream, c->sv, fp, w, level, quad_cap, thr32, coop_thr64);
+                        else
+                            hipLaunchKernelGGL((k_trace_coop<false>), dim3(cgrid), dim3(kBlock), lds_coop, c->stream, c->sv, fp, w, level, quad_cap, thr32, coop_thr64);
+                    }
                 }
                 if (profile) HIP_TRY(hipEventRecord(eb, c->stream));
                 // (the redo list - rays lying exactly in a kd split plane, exact distance ties - is re-traced inside k_shade)

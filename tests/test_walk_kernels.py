@@ -141,3 +141,45 @@ def test_counting_contexts_count_the_same_walks_in_both_kernels(monkeypatch):
         finally:
             ctx.close()
     assert got["quad"] == got["coop64"] and got["quad"][0] > 100000, got
+
+
+def test_a_wrong_guess_from_the_last_call_costs_no_ray(monkeypatch):
+    """A call launches only ONE walk kernel per level once the last call of its shape has reported its list lengths (render_frame:
+    walk_mode).  When the view then changes abruptly the guess is wrong - k_trace_coop alone meets lists of a few rays, k_trace_quad
+    alone meets long ones - and the frames must still be the ones a context that never guesses renders."""
+    import torch
+    sd = scenes.config(3, cam_z=2.4)[0]
+    hs = host.HostScene(sd)
+    desc = hs.flatten()
+    w, h = 224, 126
+    prm = device.make_params(w, h, 3)
+    near = hs.camera(w, h)                                              # the bunny fills the view: ~10 000 listed rays per level
+    away = hs.camera_at((0.0, 3.0, 2.4), (0.0, 0.3, 1.0), w, h)          # sky only: nothing listed
+    plane = hs.camera_at((0.0, 0.6, 6.0), (0.0, -0.25, -1.0), w, h)      # mostly the checker plane: a few hundred shadow rays near the model
+    hs.camera(w, h)
+    seq = [near, near, near, away, away, near, plane, near, away, plane, plane, near]
+    for k in ("RTHIP_COOP_T32", "RTHIP_COOP_T64"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("RTHIP_QUAD_COOP", "0")
+    ref_ctx = device.Context(0)
+    monkeypatch.setenv("RTHIP_QUAD_COOP", "1")
+    monkeypatch.setenv("RTHIP_COOP_T32", "3000")
+    monkeypatch.setenv("RTHIP_COOP_T64", "6000")
+    ctx = device.Context(0)
+    try:
+        ref_ctx.upload(desc)
+        ctx.upload(desc)
+        a = torch.zeros(w * h, dtype=torch.int32, device="cuda")
+        b = torch.zeros(w * h, dtype=torch.int32, device="cuda")
+        listed = set()
+        for k, cam in enumerate(seq):
+            ref_ctx.render_device(cam, prm, a.data_ptr(), sync=True)
+            ctx.render_device(cam, prm, b.data_ptr(), sync=True)
+            assert torch.equal(a, b), f"call {k}: {int((a != b).sum())} pixels differ"
+            ra, rb = ref_ctx.stats(), ctx.stats()
+            assert (ra.rays_primary, ra.rays_shadow, ra.rays_reflect, ra.rays_hard) == (rb.rays_primary, rb.rays_shadow, rb.rays_reflect, rb.rays_hard)
+            listed.add(int(rb.rays_hard) > 4 * 1.4 * 3000)
+        assert listed == {False, True}, "the views no longer fall on both sides of the threshold"
+    finally:
+        ref_ctx.close()
+        ctx.close()
