@@ -237,7 +237,8 @@ typedef struct {
     uint64_t pixels;                                   /* pixels rendered by this context */
     float ms_total;                                    /* device time of the last render (HIP events) */
     float ms_trace;                                    /* summed duration of the dominant kernel (RTHIP_PROFILE_LAUNCHES=1): the
-                                                        * mesh-walk kernel k_trace_quad (accel = 0) or k_trace (accel = 1) */
+                                                        * mesh-walk kernel - k_trace_quad / k_trace_coop, whichever the level's list
+                                                        * took (both launches are inside the bracket) - or k_trace (accel = 1) */
     uint32_t launches_trace;                           /* number of launches of that kernel (= recursion levels traced) */
     uint32_t pad;
     /* only collected by contexts created with RTHIP_COUNTERS=1 in the environment.  The traversal counters count the structure

@@ -9,9 +9,13 @@
 //                      with a wave ballot + prefix popcount and ONE atomic per workgroup); the others are
 //                      listed together with their closest hit over the analytic shapes.
 //   k_trace_quad     : the listed rays, FOUR LANES PER RAY over the 4-wide BVH (namespace quad), exact fp64
-//                      triangle tests; writes hit records.
-//   k_trace<true,.>  : redo list (rays only the reference kd-tree reproduces); normally empty.
-//   k_shade<true>    : shading + spawn of the listed rays from their hit records.
+//                      triangle tests; writes hit records.  16 rays per wave, everything of a ray in its quad.
+//   k_trace_coop     : the same for LONG lists of scenes whose trees stay in L2 (namespace coop): up to 64 rays per
+//                      wave, one ray per lane for whatever is per-ray work (transforms, hit record, shadow set-up,
+//                      analytic shadow casters), the mesh walks 16 rays at a time through quad::mesh_closest.
+//                      (Which of the two a level launches: render_frame, walk_mode.)
+//   k_shade<true>    : shading + spawn of the listed rays from their hit records; its first workgroups re-trace
+//                      the redo list (rays only the reference kd-tree reproduces; normally empty).
 // then k_resolve: per pixel, C_k = direct_k (+) C_{k+1} (x) refl_k folded back to front along the pixel's
 // chain of rays (clamping Color algebra forbids a forward throughput product), 3x3 SSAA
 // sum, 0xAABBGGRR pack.  accel = 1 runs k_trace<false,.> + k_shade<false> instead (reference kd-tree,
