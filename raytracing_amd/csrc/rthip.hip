@@ -104,6 +104,12 @@ static std::mutex g_scratch_mutex;
 #ifndef RT_QUAD_OCC
 #define RT_QUAD_OCC 5
 #endif
+#ifndef RT_COOP_OCC
+// k_trace_coop: 4 (121 VGPRs, nothing spilled).  At 5 (96 VGPRs) 43 registers of the per-ray phases live in scratch memory and the
+// kernel waits for them (VALU issue 62 % against k_trace_quad's 75 %): 32-frame calls 12 290 - 12 390 -> 12 540 Mrays/s, 20-step
+// bursts 11 720 -> 12 000; at 6 (80 VGPRs, 70 spilled) 11 920 / 11 270 (profiles/r03_coop_walk.txt)
+#define RT_COOP_OCC 4
+#endif
 #ifndef RT_SHADE_OCC
 #define RT_SHADE_OCC 4
 #endif
@@ -1385,7 +1391,7 @@ __device__ __forceinline__ void cast_analytic_any(const SceneView &sv, V3 o, V3 
 
 // Lists shorter than thr32 are k_trace_quad's (launched just before: one of the two kernels returns at once).  Both paths in ONE
 // kernel had the quad code's walk loops spill (their registers are allocated together): a lone frame 2.6 % slower.
-template <bool COUNT, int OCC = RT_QUAD_OCC>
+template <bool COUNT, int OCC = RT_COOP_OCC>
 __global__ __launch_bounds__(kBlock, OCC) void k_trace_coop(SceneView sv, FrameParams fp, Work w, uint32_t level, uint32_t stack_cap,
                                                             uint32_t thr32, uint32_t thr64) {
     const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
