@@ -55,8 +55,8 @@ def _newest(*names):
     return os.path.join("profiles", names[0])
 
 
-PMC_CFG3 = _newest("r03d_pmc_summary_config3_batch32.json", "r03_pmc_summary_config3_batch32.json", "r03_pmc_summary_config3_batch8.json", "r02_pmc_summary_config3_batch8.json")
-PMC_CFG4 = _newest("r03_pmc_summary_config4.json", "r02_pmc_summary_config4.json")
+PMC_CFG3 = _newest("r03e_pmc_summary_config3_batch32.json", "r03_pmc_summary_config3_batch32.json", "r03_pmc_summary_config3_batch8.json", "r02_pmc_summary_config3_batch8.json")
+PMC_CFG4 = _newest("r03e_pmc_summary_config4.json", "r03_pmc_summary_config4.json", "r02_pmc_summary_config4.json")
 PMC_CFG5 = _newest("r03_pmc_summary_config5.json")
 
 # ALGORITHMIC flops of the dominant kernel (SURVEY.md §8d "ALGORITHMIC flops per ray": fixed weights x measured counts), for
