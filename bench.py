@@ -55,9 +55,9 @@ def _newest(*names):
     return os.path.join("profiles", names[0])
 
 
-PMC_CFG3 = _newest("r03e_pmc_summary_config3_batch32.json", "r03_pmc_summary_config3_batch32.json", "r03_pmc_summary_config3_batch8.json", "r02_pmc_summary_config3_batch8.json")
-PMC_CFG4 = _newest("r03e_pmc_summary_config4.json", "r03_pmc_summary_config4.json", "r02_pmc_summary_config4.json")
-PMC_CFG5 = _newest("r03_pmc_summary_config5.json")
+PMC_CFG3 = _newest("r03f_pmc_summary_config3_batch32.json", "r03e_pmc_summary_config3_batch32.json", "r03_pmc_summary_config3_batch32.json", "r03_pmc_summary_config3_batch8.json", "r02_pmc_summary_config3_batch8.json")
+PMC_CFG4 = _newest("r03f_pmc_summary_config4.json", "r03e_pmc_summary_config4.json", "r03_pmc_summary_config4.json", "r02_pmc_summary_config4.json")
+PMC_CFG5 = _newest("r03f_pmc_summary_config5.json", "r03_pmc_summary_config5.json")
 
 # ALGORITHMIC flops of the dominant kernel (SURVEY.md §8d "ALGORITHMIC flops per ray": fixed weights x measured counts), for
 # k_trace_quad's units of work:
@@ -101,9 +101,9 @@ def material_flops(desc_ptr):
 
 
 def walk_kernel(ctx):
-    """the kernel that walks the meshes for this context's scene: k_trace_coop (per-ray work one ray per lane, up to 64 rays per wave;
-    scenes whose trees stay in L2, lists of >= 300 000 rays) or k_trace_quad (everything of a ray in its quad: big trees, short lists).
-    Both are launched for a small-tree scene and one returns at once; the times below bracket the pair."""
+    """the kernel that walks the meshes of this context's long lists (>= 300 000 rays per level): k_trace_coop (per-ray work one ray per
+    lane, up to 64 rays per wave) unless RTHIP_QUAD_COOP=0 forces k_trace_quad (everything of a ray in its quad), which also takes the
+    short lists.  Until a call has reported its list lengths both are launched and one returns at once; the times below bracket the pair."""
     return "k_trace_coop" if ctx.upload_info().walk_coop else "k_trace_quad"
 
 
@@ -296,17 +296,30 @@ def cpu_baseline(sd, frames=5):
     return out
 
 
-def hbm_roofline(pmc_rel, kernel="k_trace_quad<false>"):
-    """HBM roof of a kernel from a committed PMC summary: bytes per frame (FETCH_SIZE x 2 + WRITE_SIZE, separate passes) over the
-    kernel's own time in the same passes"""
-    k = _pmc_kernel(_load(pmc_rel), kernel)
+def hbm_roofline(pmc_rel, kernel=None):
+    """HBM roof of the walk kernel from a committed PMC summary: bytes per frame (FETCH_SIZE x 2 + WRITE_SIZE, separate passes) over the
+    kernel's own time in the same passes.  kernel = None: whichever of the two walk kernels did the work in that summary (the long lists of
+    a 4K / 8K frame are k_trace_coop's, the short ones of its deep levels k_trace_quad's: the larger one is reported, the other's share named)"""
+    j = _load(pmc_rel)
+    other = None
+    if kernel is None:
+        cands = [(n, _pmc_kernel(j, n + "<false>")) for n in ("k_trace_coop", "k_trace_quad")]
+        cands = [(n, k) for n, k in cands if k and k.get("hbm_bytes_per_frame")]
+        if not cands:
+            return None
+        cands.sort(key=lambda nk: -nk[1]["gpu_ms_per_frame_serialised"])
+        kernel, k = cands[0][0] + "<false>", cands[0][1]
+        if len(cands) > 1:
+            other = {"kernel": cands[1][0], "kernel_ms_per_frame": cands[1][1]["gpu_ms_per_frame_serialised"], "traffic": cands[1][1]["hbm_bytes_per_frame"]}
+    else:
+        k = _pmc_kernel(j, kernel)
     if not (k and k.get("hbm_bytes_per_frame")):
         return None
     gbs = k["hbm_bytes_per_frame"] / (k["gpu_ms_per_frame_serialised"] * 1e-3) / 1e9
     return {"bound": "hbm", "kernel": kernel.split("<")[0], "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
             "traffic": k["hbm_bytes_per_frame"], "kernel_ms_per_frame": k["gpu_ms_per_frame_serialised"],
             "valu_issue_util": k.get("valu_issue_util"), "active_lanes_per_valu_inst": k.get("active_lanes_per_valu_inst"),
-            "l2_hit_rate": k.get("l2_hit_rate"), "source": pmc_rel}
+            "l2_hit_rate": k.get("l2_hit_rate"), **({"short_lists": other} if other else {}), "source": pmc_rel}
 
 
 def config4_line(local_rank, frames=5):

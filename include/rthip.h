@@ -455,8 +455,8 @@ int rthip_probe_kd(rthip_ctx *ctx, uint32_t mesh, rthip_mesh *out_mesh, rthip_kd
 /* what the last rthip_upload_scene* of this context built on the device */
 typedef struct {
     uint32_t kd_meshes, kd_nodes, kd_levels;        /* meshes whose kd-tree was built on the device; their nodes; the deepest tree's levels */
-    uint32_t walk_coop;                             /* 1: long lists of rays that need a mesh walk go through k_trace_coop (one ray per lane outside the walks; scenes
-                                                     * whose trees stay in L2), 0: every list through k_trace_quad */
+    uint32_t walk_coop;                             /* 1: long lists of rays that need a mesh walk go through k_trace_coop (one ray per lane outside the walks; every
+                                                     * scene with meshes unless RTHIP_QUAD_COOP / RTHIP_COOP_MAX_TREE_MB say otherwise), 0: every list through k_trace_quad */
     uint64_t kd_refs;
     float kd_device_ms;                             /* device time of those builds (events around them) */
     uint32_t bvh_meshes, bvh_nodes;                 /* meshes whose BVH was built on the device; their nodes */

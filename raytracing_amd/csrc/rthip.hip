@@ -10,7 +10,7 @@
 //                      listed together with their closest hit over the analytic shapes.
 //   k_trace_quad     : the listed rays, FOUR LANES PER RAY over the 4-wide BVH (namespace quad), exact fp64
 //                      triangle tests; writes hit records.  16 rays per wave, everything of a ray in its quad.
-//   k_trace_coop     : the same for LONG lists of scenes whose trees stay in L2 (namespace coop): up to 64 rays per
+//   k_trace_coop     : the same for LONG lists (>= 300 000 rays; namespace coop): up to 64 rays per
 //                      wave, one ray per lane for whatever is per-ray work (transforms, hit record, shadow set-up,
 //                      analytic shadow casters), the mesh walks 16 rays at a time through quad::mesh_closest.
 //                      (Which of the two a level launches: render_frame, walk_mode.)
@@ -1211,8 +1211,9 @@ __global__ __launch_bounds__(kBlock, OCC) void k_trace_quad(SceneView sv, FrameP
 // needs the walk of the (wave-uniform) mesh publish the mesh-local ray in LDS, and the wave walks them 16 at a time
 // (quad::mesh_closest, unchanged: quad g takes the g-th waiting ray), the results going back to the owners' lanes.  Rays that
 // do not need a walk (missed the mesh's ball, answered by an analytic shape, no shadow query at all) take no quad's place.
-// Rays per wave: 64 when the list is long enough to fill the GPU that way, 32 / 16 for shorter lists (a wave's walks are
-// serial: a short list spread over few waves would only lengthen the level's chain).
+// Rays per wave: 64 when the list is long enough to fill the GPU that way, 32 for shorter ones; lists below 300 000 rays stay
+// with k_trace_quad (a wave's rounds of walks are serial: a short list dealt 64 at a time would end with a few waves still
+// walking while the SIMDs idle).
 namespace coop {
 static const uint32_t kRecWords = 13;  // lo, ld (12 words) + t_stop: an odd stride, so 64 lanes' word k fall in 64 different banks
 __host__ __device__ __forceinline__ uint32_t wave_bytes(uint32_t stack_cap) {  // 16 stacks, 64 records, 16 source lanes
@@ -1417,7 +1418,9 @@ __global__ __launch_bounds__(kBlock, OCC) void k_trace_coop(SceneView sv, FrameP
     const uint32_t gw = blockIdx.x * (kBlock / 64u) + wid, n_waves = gridDim.x * (kBlock / 64u);
     uint32_t it = 0;
     for (uint32_t base = gw * R; base < n; base += n_waves * R) {  // (wave-uniform)
-        if ((++it & (kIrqEvery - 1u)) == 0u && __builtin_amdgcn_readfirstlane((int)irq_load(w))) break;  // Interrupt(): see k_trace
+        // Interrupt(): see k_trace.  Every second iteration: one of this kernel's iterations is 64 rays through two queries each, four
+        // of k_trace_quad's, and on its smaller grid a wave makes more of them (a 4096 x 4096 frame: ten per wave and level)
+        if ((++it & 1u) == 0u && __builtin_amdgcn_readfirstlane((int)irq_load(w))) break;
         const uint32_t j = base + lane;
         const bool live = lane < R && j < n;
         const uint32_t i = live ? w.hard[j] : 0u;
@@ -1806,9 +1809,9 @@ struct rthip_ctx {
     uint32_t bs_stride = 0, bs_levels = 0;
     uint32_t n_tables = 0;
     bool has_meshes = false;
-    bool walk_coop = false;  // hard rays through k_trace_coop (per-ray work one ray per lane) instead of k_trace_quad: trees that stay in L2
+    bool walk_coop = false;  // long hard lists through k_trace_coop (per-ray work one ray per lane) instead of k_trace_quad
     int coop_forced = -1;    // RTHIP_QUAD_COOP
-    size_t coop_max_bytes = (size_t)8 << 20;
+    size_t coop_max_bytes = 0;
     uint32_t coop_thr32 = 300000u, coop_thr64 = 600000u;
     int mesh_without_bvh = -1;  // first mesh that has triangles but no BVH (a caller that supplied only the kd-tree), -1 = none
     std::atomic<int> interrupt{0};
@@ -1920,7 +1923,7 @@ int rthip_create(int device, rthip_ctx **out) {
     env = getenv("RTHIP_QUAD_COOP");
     c->coop_forced = env ? (atoi(env) != 0 ? 1 : 0) : -1;
     env = getenv("RTHIP_COOP_MAX_TREE_MB");
-    c->coop_max_bytes = (size_t)(env && atoi(env) > 0 ? atoi(env) : 8) << 20;
+    c->coop_max_bytes = (size_t)(env && atoi(env) > 0 ? atoi(env) : 0) << 20;  // (0: no limit)
     env = getenv("RTHIP_COOP_T32");
     c->coop_thr32 = env && atoi(env) > 0 ? (uint32_t)atoi(env) : 300000u;
     env = getenv("RTHIP_COOP_T64");
@@ -2390,10 +2393,13 @@ static int upload_scene_impl(rthip_ctx *c, const rthip_scene_desc *s, bool keep_
     c->mesh_without_bvh = -1;
     for (uint32_t i = 0; i < s->n_meshes; i++)
         if (c->mesh_table[i].tri_count && !c->mesh_table[i].bvh_node_count && c->mesh_without_bvh < 0) c->mesh_without_bvh = (int)i;
-    {   // which walk kernel serves this scene (see k_trace_coop): the footprint of what the walks read
+    {   // Which walk kernel serves this scene's LONG lists: k_trace_coop, for every scene with meshes.  Measured: the bunny +8 % (its
+        // short walks leave the per-ray work a 40 % share), config 5's five meshes -6.4 % of a frame (a transform per mesh and query),
+        // config 4's one 2 M-triangle mesh +-0.3 % (walks that wait for HBM).  RTHIP_QUAD_COOP=0 / 1 forces it; RTHIP_COOP_MAX_TREE_MB=<n>
+        // restricts it to scenes whose BVH nodes + leaf-order triangles take at most n MB (0 = no limit, the default).
         size_t bytes = 0;
         for (const rthip_mesh &m : c->mesh_table) bytes += (size_t)m.bvh_node_count * sizeof(rthip_bvhnode) + (size_t)m.tri_count * (sizeof(rthip_tri) + 4u);
-        c->walk_coop = c->coop_forced >= 0 ? c->coop_forced == 1 : bytes <= c->coop_max_bytes;
+        c->walk_coop = c->coop_forced >= 0 ? c->coop_forced == 1 : (c->has_meshes && (c->coop_max_bytes == 0 || bytes <= c->coop_max_bytes));
     }
     v.bg = s->background;
     c->stack_cap_kd = max_depth + 2;
@@ -2580,7 +2586,7 @@ static int render_frame(rthip_ctx *c, const rthip_camera *cam, uint32_t n_frames
         HIP_TRY(hipFuncSetAttribute((const void *)k_trace_quad<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_quad));
         HIP_TRY(hipFuncSetAttribute((const void *)k_trace_quad<false, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_quad));
     }
-    // the walk kernel with one ray per lane outside the walks (k_trace_coop) when the scene's trees are small (upload_scene)
+    // the walk kernel with one ray per lane outside the walks (k_trace_coop) for the long lists (upload_scene: walk_coop)
     const bool quad_coop = c->walk_coop && !quad_occ6;
     // Which of the two walk kernels a level launches.  The length of its list is on the device, so a scene with small trees gets
     // both and one returns at once (~2.5 us of a lone frame's chain per level) - unless the last call of this very shape (frames,

@@ -183,3 +183,28 @@ def test_a_wrong_guess_from_the_last_call_costs_no_ray(monkeypatch):
     finally:
         ref_ctx.close()
         ctx.close()
+
+
+def test_which_kernel_a_scenes_long_lists_get(monkeypatch):
+    """rthip_upload_info.walk_coop: every scene with meshes has its long lists walked by k_trace_coop (the bunny +8 %, config 5's five
+    meshes -6 % of a frame, config 4's one big mesh unchanged: profiles/r03_coop_walk.txt); RTHIP_COOP_MAX_TREE_MB restricts that to
+    scenes whose trees (BVH nodes + leaf-order triangles) fit, RTHIP_QUAD_COOP forces either side"""
+    for k in ("RTHIP_QUAD_COOP", "RTHIP_COOP_MAX_TREE_MB"):
+        monkeypatch.delenv(k, raising=False)
+    keep = [host.HostScene(scenes.config(3)[0]),                          # the bunny: 4 968 triangles, 0.8 MB
+            host.HostScene(scenes.config(4, cells=200)[0]),               # 80 000 triangles: ~13 MB
+            host.HostScene(scenes.config(2)[0])]                          # (the descriptors point into these objects)
+    small, big, no_mesh = (hs.flatten() for hs in keep)
+
+    def side(desc):
+        ctx = device.Context(0)
+        try:
+            ctx.upload(desc)
+            return int(ctx.upload_info().walk_coop)
+        finally:
+            ctx.close()
+    assert side(small) == 1 and side(big) == 1 and side(no_mesh) == 0
+    monkeypatch.setenv("RTHIP_COOP_MAX_TREE_MB", "8")
+    assert side(small) == 1 and side(big) == 0
+    monkeypatch.setenv("RTHIP_QUAD_COOP", "0")
+    assert side(small) == 0
