@@ -582,12 +582,21 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    # warm-up: at least three calls per context of every call size the timed region uses (workspaces allocated; the
-    # library captures a frame's launch graph the second time it is asked for and replays it from the third)
+    # warm-up: at least five calls per context of every call size the timed region uses (workspaces allocated; the library
+    # captures a call's launch graph the second time it sees that launch sequence and replays it from the third - and the
+    # sequence changes once, when the first calls have reported their list lengths and only one walk kernel per level is
+    # launched from then on: so two calls per context, a wait for their reports, then three more)
+    run_frames(2 * F * B)
+    sync_local()
     run_frames(max(args.warmup, 3 * F * B))
+    sync_local()
     if args.steps % B:
+        for j in range(2 * F):
+            call(j, args.steps % B)
+        sync_local()
         for j in range(3 * F):
             call(j, args.steps % B)
+        sync_local()
     # The timed region: exactly --steps frames between a barrier + synchronize (all ranks start together) and this rank's own
     # synchronize; the slowest rank's time counts (MAX over ranks below), so no second barrier sits inside the region.
     # Repeated --repeats times (default 5); `value` is the MEDIAN burst, every sample is in the line.
