@@ -195,7 +195,7 @@ struct Work {
     uint32_t N;
     // Interrupt() / RenderStatus::Percent at kernel granularity (Raytracer.cpp:91-99, 150-154): `irq` is a word in FINE-GRAINED
     // device memory (not cached in L2, so a write made while a kernel runs is seen by that kernel) raised by the watcher
-    // workgroup (irq_load); every workgroup reads it when it starts and once per grid-stride iteration and leaves when it is
+    // workgroups (irq_load); every workgroup reads it when it starts and once per grid-stride iteration and leaves when it is
     // set.  `stage` is a word in page-locked host memory: workgroup 0 of every kernel stores the index of the stage it begins.
     const uint32_t *irq;
     const uint32_t *irq_host;   // the request itself: a word in page-locked host memory that rthip_interrupt stores to
@@ -206,12 +206,18 @@ struct Work {
     uint32_t *hist;
     uint32_t hist_tag;
 };
-// Workgroup 0 of every kernel is the watcher: it reads the request word in host memory (a PCIe read, so only this one workgroup
-// does it, once per grid-stride iteration - its iterations are spread over the kernel's whole run) and raises the device-side
-// flag; everybody polls that flag, which costs an uncached read of HBM.  (Raising the device flag from the host with
-// hipMemsetAsync / hipMemcpyAsync on a side stream waited for a free slot on a saturated GPU: 20 ms.)
+// Every 1024th workgroup of every kernel is a watcher: it reads the request word in host memory (a PCIe read of a microsecond or
+// two that its whole workgroup waits for, so only a handful of workgroups do it, once per poll) and raises the device-side flag;
+// everybody polls that flag, which costs an uncached read of HBM.  (Raising the device flag from the host with hipMemsetAsync /
+// hipMemcpyAsync on a side stream waited for a free slot on a saturated GPU: 20 ms.)
+// Not workgroup 0 alone: where a grid is several times what the GPU holds at once, workgroup 0 has finished its share after the
+// first of those rounds, and a request that arrived later in the kernel's run was relayed by the NEXT kernel (round 3,
+// tools/gpu_irq_probe3.py; profiles/r03_interrupt_watchers.txt).  Not every 64th either: those watchers' PCIe reads cost 6 % of the
+// headline rate (same file); with every 1024th the rate is that of the single watcher and a walk kernel leaves 0.2-0.4 ms after
+// Interrupt().
+static const uint32_t kWatcherEvery = 1024;  // (a power of two)
 __device__ __forceinline__ uint32_t irq_load(const Work &w) {
-    if (blockIdx.x == 0 && __hip_atomic_load(w.irq_host, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM))
+    if ((blockIdx.x & (kWatcherEvery - 1u)) == 0u && __hip_atomic_load(w.irq_host, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM))
         __hip_atomic_store(const_cast<uint32_t *>(w.irq), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     return __hip_atomic_load(w.irq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
@@ -1418,9 +1424,10 @@ __global__ __launch_bounds__(kBlock, OCC) void k_trace_coop(SceneView sv, FrameP
     const uint32_t gw = blockIdx.x * (kBlock / 64u) + wid, n_waves = gridDim.x * (kBlock / 64u);
     uint32_t it = 0;
     for (uint32_t base = gw * R; base < n; base += n_waves * R) {  // (wave-uniform)
-        // Interrupt(): see k_trace.  Every second iteration: one of this kernel's iterations is 64 rays through two queries each, four
-        // of k_trace_quad's, and on its smaller grid a wave makes more of them (a 4096 x 4096 frame: ten per wave and level)
-        if ((++it & 1u) == 0u && __builtin_amdgcn_readfirstlane((int)irq_load(w))) break;
+        // Interrupt(): see k_trace.  EVERY iteration but the first: one of this kernel's iterations is 64 rays through two queries each
+        // (0.1 - 0.7 ms), and a wave makes only a few of them per level - polled every eighth (or second) iteration most waves of
+        // a 4096 x 4096 frame never looked again, and an Interrupt() took 10 ms of a 26 ms frame to be noticed
+        if (it++ && __builtin_amdgcn_readfirstlane((int)irq_load(w))) break;
         const uint32_t j = base + lane;
         const bool live = lane < R && j < n;
         const uint32_t i = live ? w.hard[j] : 0u;
@@ -1571,7 +1578,8 @@ __global__ __launch_bounds__(kBlock, RT_SHADE_OCC) void k_shade(SceneView sv, Fr
             const uint32_t n_shadow = fp.renderer == RTHIP_RENDER_RAYTRACER ? sv.n_lights : 0u;
             it = 0;
             for (uint32_t base = blockIdx.x * kBlock; base < n_redo; base += busy * kBlock) {
-                if ((it++ & (kIrqEvery - 1u)) == 0u) {
+                {   // Interrupt(): EVERY iteration - one of them is 256 rays through the reference's kd walk (on a height field seen along
+                    // its grid lines the pass takes milliseconds on its 64 workgroups; polled every eighth iteration it never looked again)
                     if (threadIdx.x == 0) sh.irq = irq_load(w);
                     __syncthreads();
                     if (sh.irq) break;
