@@ -53,6 +53,10 @@ struct SceneView {
     const rthip_light *lights;
     uint32_t n_lights;
     rthip_background bg;
+    // [n_lights][n_shapes][3]: the direction of a DIRECTIONAL light in the frame of every shape, normalized(inv * direction) - what
+    // Scene::CastRay computes per (shadow ray, shape) although it is the same for every ray; filled at upload by a kernel that runs
+    // the same functions (rthip.hip: k_light_dirs), so bit for bit what a lane would compute.  nullptr: not available.
+    const double *shadow_ld = nullptr;
 };
 
 // Shape and light records are indexed by wave-uniform loop counters.  On the device they are read

@@ -427,6 +427,38 @@ __global__ __launch_bounds__(kBlock, RT_TRACE_OCC) void k_trace(SceneView sv, Fr
 // step), divides the lanes whose slowest member a wave waits for by four, and turns 64 scattered
 // 64-byte gathers per wave-load into 16 full lines.  Every branch that encloses a cross-lane
 // operation is quad-uniform by construction (ray state is replicated bit-identically in the 4 lanes).
+// A directional light's shadow rays all have the same direction, so their direction in a shape's frame - normalized(inv * d):
+// two dozen multiply-adds, a square root and three divisions, ~96 instructions per (ray, shape) - is a property of the (light,
+// shape) pair: k_light_dirs computes it once at upload with the functions the kernels would use (SceneView::shadow_ld), and a
+// shadow query towards such a light reads its three doubles through the scalar cache.  `row`: the light's row of the table,
+// or nullptr (closest-hit queries, point lights).
+typedef const __attribute__((address_space(4))) double rt_uniform_double;
+__device__ __forceinline__ const double *shadow_ld_row(const SceneView &sv, uint32_t light, int32_t ltype) {
+    return (ltype == RTHIP_LIGHT_DIRECTIONAL && sv.shadow_ld) ? sv.shadow_ld + (size_t)light * sv.n_shapes * 3u : nullptr;
+}
+__device__ __forceinline__ V3 local_dir(const double *row, uint32_t s, const double *inv, V3 d) {
+    if (row) {  // (wave-uniform)
+        rt_uniform_double *t = (rt_uniform_double *)row + 3u * s;
+        return mk(t[0], t[1], t[2]);
+    }
+    return normalized(xform(inv, d, 0.0));
+}
+__global__ void k_light_dirs(SceneView sv, double *out) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= sv.n_lights * sv.n_shapes) return;
+    const uint32_t l = k / sv.n_shapes, s = k % sv.n_shapes;
+    const rthip_light &light = sv.lights[l];
+    V3 r = mk(0, 0, 0);
+    if (light.type == RTHIP_LIGHT_DIRECTIONAL) {
+        double inv[12];
+        for (int j = 0; j < 12; j++) inv[j] = sv.shapes[s].inv[j];
+        r = normalized(xform(inv, mk(light.direction[0], light.direction[1], light.direction[2]), 0.0));
+    }
+    out[3 * (size_t)k] = r.x;
+    out[3 * (size_t)k + 1] = r.y;
+    out[3 * (size_t)k + 2] = r.z;
+}
+
 namespace quad {
 constexpr int kXor1 = 0xB1, kXor2 = 0x4E, kRot1 = 0x39, kRot3 = 0x93;  // quad_perm [1,0,3,2] [2,3,0,1] [1,2,3,0] [3,0,1,2]
 static const uint32_t kRaysPerBlock = kBlock / 4;
@@ -671,7 +703,7 @@ struct Park {
 // `known`: the query over the analytic shapes has been answered already (k_trace_easy, closest-hit query only).
 template <bool COUNT>
 __device__ __forceinline__ int32_t cast_ray(const SceneView &sv, Park park, Stack qs, uint32_t q, bool any_hit, bool active,
-                                            const PendRec *known, int32_t &best_tri, bool &redo, KdCounters &cnt) {
+                                            const PendRec *known, int32_t &best_tri, bool &redo, KdCounters &cnt, const double *ld_row = nullptr) {
     double bd = known ? known->bd : DBL_MAX;
     uint32_t bs = known ? known->bs : 0xffffffffu;
     best_tri = -1;
@@ -692,7 +724,7 @@ __device__ __forceinline__ int32_t cast_ray(const SceneView &sv, Park park, Stac
             if (type == RTHIP_SHAPE_SPHERE && ball_missed(sh.bound_c[0], sh.bound_c[1], sh.bound_c[2], sh.bound_r2, o, d)) continue;
             if (COUNT) cnt.shapes_full++;
             V3 lo = xform(sh.inv, o, 1.0);
-            V3 ld = normalized(xform(sh.inv, d, 0.0));
+            V3 ld = ld_row ? mk(ld_row[3u * s], ld_row[3u * s + 1u], ld_row[3u * s + 2u]) : normalized(xform(sh.inv, d, 0.0));  // (see local_dir; s differs per lane here)
             V3 p;
             bool hit = type == RTHIP_SHAPE_SPHERE ? sphere_intersect(lo, ld, p)
                                                   : plane_intersect(mk(sh.plane_n[0], sh.plane_n[1], sh.plane_n[2]), lo, ld, p);
@@ -727,7 +759,7 @@ __device__ __forceinline__ int32_t cast_ray(const SceneView &sv, Park park, Stac
 #pragma unroll
             for (int k = 0; k < 12; k++) inv[k] = sh->inv[k];
             lo = xform(inv, o, 1.0);
-            ld = normalized(xform(inv, d, 0.0));
+            ld = local_dir(ld_row, s, inv, d);
         }
         const rthip_mesh m = rt_load_mesh(sv.meshes + sh->mesh);
         if (kd_degenerate_ray(sv, m, lo, ld)) {
@@ -808,7 +840,7 @@ __device__ __forceinline__ bool trace_stage(const SceneView &sv, Park park, uint
             rd = normalized(sub(mk(light->position[0], light->position[1], light->position[2]), park.o()));
         park.put_d(rd);
         int32_t tri;
-        const int32_t shape = cast_ray<COUNT>(sv, park, qs, q, true, active, nullptr, tri, redo, cnt);
+        const int32_t shape = cast_ray<COUNT>(sv, park, qs, q, true, active, nullptr, tri, redo, cnt, shadow_ld_row(sv, l, ltype));
         if (shape >= 0) out_mask |= 1u << l;
     }
     return !redo;
@@ -979,7 +1011,7 @@ __device__ __forceinline__ bool mesh_may_hit(const SceneView &sv, const rthip_me
 // rtc::cast_ray_id restricted to the analytic shapes; `hard` is set when a mesh would have to be walked
 template <bool COUNT>
 __device__ __forceinline__ int32_t cast_ray(const SceneView &sv, V3 o, V3 d, bool any_hit, bool active, bool &hard, double &hitDistance,
-                                            KdCounters &cnt) {
+                                            KdCounters &cnt, const double *ld_row) {
     int32_t best = -1;
     hitDistance = DBL_MAX;
     bool mesh_box = false;
@@ -994,7 +1026,7 @@ __device__ __forceinline__ int32_t cast_ray(const SceneView &sv, V3 o, V3 d, boo
 #pragma unroll
         for (int k = 0; k < 12; k++) inv[k] = sh->inv[k];
         V3 lo = xform(inv, o, 1.0);
-        V3 ld = normalized(xform(inv, d, 0.0));
+        V3 ld = local_dir(ld_row, s, inv, d);
         if (type == RTHIP_SHAPE_MESH) {
             if (!mesh_box) mesh_box = mesh_may_hit(sv, rt_load_mesh(sv.meshes + sh->mesh), lo, ld);
             continue;
@@ -1033,11 +1065,13 @@ __device__ __forceinline__ bool trace_stage(const SceneView &sv, V3 o, V3 d, uin
     for (int32_t l = -1; l < (int32_t)n_shadow_lights; l++) {
         V3 ro = o, rd = d;
         bool active = live && !hard;
+        const double *ld_row = nullptr;
         if (l >= 0) {
             const rt_uniform_light *light = rt_uniform_cast(sv.lights) + l;
             const int32_t ltype = light->type;
             if (!light->enabled || ltype == RTHIP_LIGHT_AMBIENT) continue;  // Raytracer.cpp:213, 234-237
             active = active && h.shape >= 0;
+            ld_row = shadow_ld_row(sv, (uint32_t)l, ltype);
             ro = point;
             if (ltype == RTHIP_LIGHT_DIRECTIONAL)
                 rd = mk(light->direction[0], light->direction[1], light->direction[2]);
@@ -1045,7 +1079,7 @@ __device__ __forceinline__ bool trace_stage(const SceneView &sv, V3 o, V3 d, uin
                 rd = normalized(sub(mk(light->position[0], light->position[1], light->position[2]), point));
         }
         double distance;
-        const int32_t shape = cast_ray<COUNT>(sv, ro, rd, l >= 0, active, hard, distance, cnt);
+        const int32_t shape = cast_ray<COUNT>(sv, ro, rd, l >= 0, active, hard, distance, cnt, ld_row);
         if (l < 0) {
             if (shape >= 0) {
                 analytic.bd = distance;
@@ -1303,7 +1337,7 @@ __device__ __forceinline__ void walk(const SceneView &sv, const rthip_mesh &m, V
 template <bool COUNT, class RAY>
 __device__ __forceinline__ void cast_meshes(const SceneView &sv, const RAY &ray, bool any_hit, bool active, double &bd, uint32_t &bs,
                                             int32_t &best_tri, bool &redo, const Lds &L, uint32_t lane, KdCounters &cnt,
-                                            uint32_t &max_walk_nodes) {
+                                            uint32_t &max_walk_nodes, const double *ld_row = nullptr) {
     for (uint32_t s = 0; s < sv.n_shapes; s++) {
         const rt_uniform_shape *sh = rt_uniform_cast(sv.shapes) + s;
         if (sh->type != RTHIP_SHAPE_MESH) continue;
@@ -1321,7 +1355,7 @@ __device__ __forceinline__ void cast_meshes(const SceneView &sv, const RAY &ray,
 #pragma unroll
             for (int k = 0; k < 12; k++) inv[k] = sh->inv[k];
             const V3 lo = xform(inv, o, 1.0);
-            const V3 ld = normalized(xform(inv, d, 0.0));
+            const V3 ld = local_dir(ld_row, s, inv, d);
             if (want && kd_degenerate_ray(sv, m, lo, ld)) {
                 redo = true;
                 want = false;
@@ -1366,7 +1400,8 @@ __device__ __forceinline__ void cast_meshes(const SceneView &sv, const RAY &ray,
 // the analytic shapes of a shadow query, one ray per lane (quad::cast_ray's first loop; only .Hit is consumed, so the
 // first accepted shape ends the lane's search)
 template <bool COUNT>
-__device__ __forceinline__ void cast_analytic_any(const SceneView &sv, V3 o, V3 d, bool active, double &bd, uint32_t &bs, KdCounters &cnt) {
+__device__ __forceinline__ void cast_analytic_any(const SceneView &sv, V3 o, V3 d, bool active, double &bd, uint32_t &bs, KdCounters &cnt,
+                                                  const double *ld_row) {
     for (uint32_t s = 0; s < sv.n_shapes; s++) {
         const rt_uniform_shape *sh = rt_uniform_cast(sv.shapes) + s;
         const int32_t type = sh->type;
@@ -1379,7 +1414,7 @@ __device__ __forceinline__ void cast_analytic_any(const SceneView &sv, V3 o, V3 
 #pragma unroll
         for (int k = 0; k < 12; k++) inv[k] = sh->inv[k];
         const V3 lo = xform(inv, o, 1.0);
-        const V3 ld = normalized(xform(inv, d, 0.0));
+        const V3 ld = local_dir(ld_row, s, inv, d);
         V3 p;
         const bool hit = type == RTHIP_SHAPE_SPHERE ? sphere_intersect(lo, ld, p)
                                                     : plane_intersect(mk(sh->plane_n[0], sh->plane_n[1], sh->plane_n[2]), lo, ld, p);
@@ -1490,12 +1525,13 @@ __global__ __launch_bounds__(kBlock, OCC) void k_trace_coop(SceneView sv, FrameP
             double sd = DBL_MAX;
             uint32_t ss = 0xffffffffu;
             int32_t tri = -1;
+            const double *ld_row = shadow_ld_row(sv, l, ltype);
             {
                 V3 ro, rd;
                 shadow_ray(ro, rd);
-                coop::cast_analytic_any<COUNT>(sv, ro, rd, active, sd, ss, kc);
+                coop::cast_analytic_any<COUNT>(sv, ro, rd, active, sd, ss, kc, ld_row);
             }
-            coop::cast_meshes<COUNT>(sv, shadow_ray, true, active, sd, ss, tri, redo, L, lane, kc, max_walk_nodes);
+            coop::cast_meshes<COUNT>(sv, shadow_ray, true, active, sd, ss, tri, redo, L, lane, kc, max_walk_nodes, ld_row);
             if (ss != 0xffffffffu) shadow_mask |= 1u << l;
         }
         if (!live) continue;
@@ -1814,6 +1850,7 @@ struct rthip_ctx {
     uint32_t stack_cap = 1;
     // frame workspace
     DevBuf rec, child, rays, counts, stats, block_stats, ids, pixels_tmp, ids_out, hits, redo, redo_stack, pend, probe[8];
+    DevBuf shadow_ld;  // SceneView::shadow_ld
     uint32_t bs_stride = 0, bs_levels = 0;
     uint32_t n_tables = 0;
     bool has_meshes = false;
@@ -1947,7 +1984,7 @@ int rthip_destroy(rthip_ctx *c) {
     (void)hipStreamSynchronize(c->stream);
     DevBuf *all[] = {&c->shapes, &c->meshes, &c->kd_nodes, &c->kd_bounds, &c->kd_refs, &c->tris, &c->tri_normals,
                      &c->materials, &c->noises, &c->perlin, &c->worley, &c->lights, &c->rec, &c->child, &c->rays,
-                     &c->counts, &c->stats, &c->ids, &c->pixels_tmp, &c->ids_out, &c->bvh_nodes, &c->bvh_tris, &c->bvh_index, &c->kd_planes, &c->hits, &c->redo, &c->redo_stack, &c->block_stats, &c->pend};
+                     &c->counts, &c->stats, &c->ids, &c->pixels_tmp, &c->ids_out, &c->bvh_nodes, &c->bvh_tris, &c->bvh_index, &c->kd_planes, &c->hits, &c->redo, &c->redo_stack, &c->block_stats, &c->pend, &c->shadow_ld};
     for (DevBuf *b : all) b->release();
     for (DevBuf &b : c->probe) b.release();
     for (auto &g : c->graphs) (void)hipGraphExecDestroy(g.exec);
@@ -2396,6 +2433,19 @@ static int upload_scene_impl(rthip_ctx *c, const rthip_scene_desc *s, bool keep_
     v.worley_points = (const double *)c->worley.p;
     v.lights = (const rthip_light *)c->lights.p;
     v.n_lights = s->n_lights;
+    v.shadow_ld = nullptr;
+    {   // the directional lights' directions in every shape's frame (k_light_dirs); RTHIP_SHADOW_LD=0: every lane computes its own
+        const char *env = getenv("RTHIP_SHADOW_LD");  // (read at every upload: tests compare the two)
+        const bool enabled = !(env && atoi(env) == 0);
+        const size_t pairs = (size_t)s->n_lights * s->n_shapes;
+        if (enabled && pairs) {
+            if (c->shadow_ld.ensure(sizeof(double) * 3 * pairs)) return RTHIP_E_HIP;
+            hipLaunchKernelGGL(k_light_dirs, dim3((uint32_t)((pairs + 63) / 64)), dim3(64), 0, c->stream, v, (double *)c->shadow_ld.p);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            v.shadow_ld = (const double *)c->shadow_ld.p;
+        }
+    }
     c->n_tables = s->n_perlin_tables;
     c->has_meshes = s->n_meshes > 0;
     c->mesh_without_bvh = -1;

@@ -208,3 +208,36 @@ def test_which_kernel_a_scenes_long_lists_get(monkeypatch):
     assert side(small) == 1 and side(big) == 0
     monkeypatch.setenv("RTHIP_QUAD_COOP", "0")
     assert side(small) == 0
+
+
+@pytest.mark.parametrize("table", ["0", "1"])
+def test_directional_lights_local_directions_from_the_upload_table(monkeypatch, oracle_lib, table):
+    """SceneView::shadow_ld (rthip.hip: k_light_dirs): a directional light's direction in every shape's frame is computed once per
+    (light, shape) at upload instead of per (shadow ray, shape).  With the table (default) and without it (RTHIP_SHADOW_LD=0) every
+    walk kernel gives the oracle's frames: rotated / scaled meshes and spheres under several suns, a disabled sun, point lights
+    beside them (per-ray directions: no table row), nested transforms from the generator."""
+    monkeypatch.setenv("RTHIP_SHADOW_LD", table)   # (read when the scene is uploaded)
+    sd = scenes.SceneDesc("three suns, one disabled, and a point light over rotated / scaled shapes")
+    a = sd.uniform_material(0xcc8844, 0.6)
+    b = sd.uniform_material(0xffffff, 0.3)
+    v, n = scenes.heightfield_mesh(cells=24, seed=9, extent=3.0)
+    sd.mesh(a, v, n, scenes.NORMAL_VERTEX, node=sd.node(-1, (0.5, 0.0, -1.0), (0.2, 0.7, -0.1), (1.0, 1.6, 0.8)))
+    sd.mesh(b, v, n, scenes.NORMAL_FACE, node=sd.node(-1, (-2.0, 1.5, -3.0), (-0.4, 0.1, 0.9), (0.5, 0.5, 0.7)))
+    sd.scale(1.3, 0.7, 1.1); sd.position(1.5, 1.2, 0.5); sd.sphere(b)
+    sd.scale(1, 1, 1); sd.position(-1.5, 0.8, 1.0); sd.sphere(a)
+    sd.position(0, -1.2, 0); sd.plane(sd.interpolated_material(sd.checker(2), a, b), 0, 1, 0)
+    sd.directional_light(0xffeecc, 1, 2, 1)
+    sd.directional_light(0x4466ff, -2, 1, 0.5)
+    sd.directional_light(0xff0000, 0, 1, -1, enabled=0)
+    sd.point_light(0x88ff88, 9, pos=(0.5, 4, 2))
+    sd.ambient_light(0x101010)
+    sd.color_background(0x203040)
+    sd.look_at((0.5, 3.5, 7), (0, 0.3, 0))
+    ref = sd.build(oracle_lib).render(160, 100, ids=True, threads=8, max_recursion=4)
+    for mode in ("quad", "coop64", "coop32", "default"):
+        _same(_render(monkeypatch, mode, sd, 160, 100, max_recursion=4), ref, f"table {table} {mode} suns")
+    for seed in fuzz_scenes.FUZZ_SEEDS[12:20]:
+        sd = fuzz_scenes.random_scene(seed)
+        ref = sd.build(oracle_lib).render(96, 64, ids=True, threads=8, max_recursion=3)
+        for mode in ("quad", "coop64"):
+            _same(_render(monkeypatch, mode, sd, 96, 64, max_recursion=3), ref, f"table {table} {mode} fuzz {seed}")
