@@ -57,6 +57,9 @@ struct SceneView {
     // Scene::CastRay computes per (shadow ray, shape) although it is the same for every ray; filled at upload by a kernel that runs
     // the same functions (rthip.hip: k_light_dirs), so bit for bit what a lane would compute.  nullptr: not available.
     const double *shadow_ld = nullptr;
+    // [n_shapes][3]: the world-space normal of a PLANE, normalized(nrm * plane_n) - the same for every hit of it (hit_details);
+    // filled by the same kernel.  nullptr: not available.
+    const double *plane_wn = nullptr;
 };
 
 // Shape and light records are indexed by wave-uniform loop counters.  On the device they are read
@@ -1190,7 +1193,12 @@ RT_HD void hit_details(const SceneView &sv, V3 o, V3 d, int32_t shape, int32_t t
     h.tri = tri;
     h.local = p;
     h.point = xform(sh.fwd, p, 1.0);
-    h.normal = normalized(xform(sh.nrm, ln, 0.0));
+    if (sh.type == RTHIP_SHAPE_PLANE && sv.plane_wn) {  // (see SceneView::plane_wn)
+        const double *n = sv.plane_wn + 3 * (size_t)shape;
+        h.normal = mk(n[0], n[1], n[2]);
+    } else {
+        h.normal = normalized(xform(sh.nrm, ln, 0.0));
+    }
 }
 
 RT_HD Hit cast_ray(const SceneView &sv, V3 o, V3 d, KdStack &st, bool any_hit, KdCounters *cnt) {

@@ -443,8 +443,16 @@ __device__ __forceinline__ V3 local_dir(const double *row, uint32_t s, const dou
     }
     return normalized(xform(inv, d, 0.0));
 }
-__global__ void k_light_dirs(SceneView sv, double *out) {
+__global__ void k_light_dirs(SceneView sv, double *out, double *plane_wn) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < sv.n_shapes) {  // SceneView::plane_wn: hit_details' normal of a plane, the same for every hit
+        const rthip_shape &sh = sv.shapes[k];
+        V3 r = mk(0, 0, 0);
+        if (sh.type == RTHIP_SHAPE_PLANE) r = normalized(xform(sh.nrm, mk(sh.plane_n[0], sh.plane_n[1], sh.plane_n[2]), 0.0));
+        plane_wn[3 * (size_t)k] = r.x;
+        plane_wn[3 * (size_t)k + 1] = r.y;
+        plane_wn[3 * (size_t)k + 2] = r.z;
+    }
     if (k >= sv.n_lights * sv.n_shapes) return;
     const uint32_t l = k / sv.n_shapes, s = k % sv.n_shapes;
     const rthip_light &light = sv.lights[l];
@@ -2433,17 +2441,20 @@ static int upload_scene_impl(rthip_ctx *c, const rthip_scene_desc *s, bool keep_
     v.worley_points = (const double *)c->worley.p;
     v.lights = (const rthip_light *)c->lights.p;
     v.n_lights = s->n_lights;
-    v.shadow_ld = nullptr;
-    {   // the directional lights' directions in every shape's frame (k_light_dirs); RTHIP_SHADOW_LD=0: every lane computes its own
+    v.shadow_ld = v.plane_wn = nullptr;
+    {   // what is the same for every ray, once: the directional lights' directions in every shape's frame and the planes' world
+        // normals (k_light_dirs); RTHIP_SHADOW_LD=0: every lane computes its own
         const char *env = getenv("RTHIP_SHADOW_LD");  // (read at every upload: tests compare the two)
         const bool enabled = !(env && atoi(env) == 0);
-        const size_t pairs = (size_t)s->n_lights * s->n_shapes;
-        if (enabled && pairs) {
-            if (c->shadow_ld.ensure(sizeof(double) * 3 * pairs)) return RTHIP_E_HIP;
-            hipLaunchKernelGGL(k_light_dirs, dim3((uint32_t)((pairs + 63) / 64)), dim3(64), 0, c->stream, v, (double *)c->shadow_ld.p);
+        const size_t pairs = (size_t)s->n_lights * s->n_shapes, threads = pairs > s->n_shapes ? pairs : s->n_shapes;
+        if (enabled && threads) {
+            if (c->shadow_ld.ensure(sizeof(double) * 3 * (pairs + s->n_shapes))) return RTHIP_E_HIP;
+            double *ld = (double *)c->shadow_ld.p, *wn = ld + 3 * pairs;
+            hipLaunchKernelGGL(k_light_dirs, dim3((uint32_t)((threads + 63) / 64)), dim3(64), 0, c->stream, v, ld, wn);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipStreamSynchronize(c->stream));
-            v.shadow_ld = (const double *)c->shadow_ld.p;
+            v.shadow_ld = pairs ? ld : nullptr;
+            v.plane_wn = wn;
         }
     }
     c->n_tables = s->n_perlin_tables;
