@@ -1577,10 +1577,55 @@ __global__ __launch_bounds__(kBlock, OCC) void k_trace_coop(SceneView sv, FrameP
     }
     if (COUNT) trace_counters_flush(fp, w, kc, max_walk_nodes, t_start);
 }
+// The redo list (rays only the reference kd-tree reproduces: kd-degenerate (ray, mesh) pairs and exact distance ties; normally
+// empty): re-traced one ray per lane through every query (rtc::trace_stage) and shaded on the spot by `busy` workgroups (all of
+// which call this).  Stacks in global memory (w.redo_stack): the rare path takes no LDS from the common one.
+__device__ __forceinline__ void redo_pass(const SceneView &sv, const FrameParams &fp, const Work &w, const uint8_t *tabs, ShadeShared &sh,
+                                          uint32_t level, uint32_t stack_cap, uint32_t n_redo, uint32_t busy, uint32_t &shadow_total,
+                                          uint32_t &spawn_total) {
+    KdStack st = make_stack(w.redo_stack + (size_t)blockIdx.x * kBlock + threadIdx.x, kRedoBlocks * kBlock, stack_cap, nullptr);
+    const uint32_t n_shadow = fp.renderer == RTHIP_RENDER_RAYTRACER ? sv.n_lights : 0u;
+    for (uint32_t base = blockIdx.x * kBlock; base < n_redo; base += busy * kBlock) {
+        {   // Interrupt(): EVERY iteration - one of them is 256 rays through the reference's kd walk (on a height field seen along
+            // its grid lines the pass takes milliseconds on its 64 workgroups; polled every eighth iteration it never looked again)
+            if (threadIdx.x == 0) sh.irq = irq_load(w);
+            __syncthreads();
+            if (sh.irq) break;
+        }
+        const uint32_t j = base + threadIdx.x;
+        const bool live = j < n_redo;
+        const uint32_t i = live ? w.redo[j] : 0u;
+        V3 o = mk(0, 0, 0), d = mk(0, 0, 1);
+        if (live) {  // (level 0 too: k_trace_easy stored the primary rays it listed)
+            const RayRec r = ray_at(w, level, i);
+            o = mk(r.ox, r.oy, r.oz);
+            d = mk(r.dx, r.dy, r.dz);
+        }
+        HitRec h;
+        h.shape = -1;
+        h.tri = -1;
+        h.shadow_mask = 0;
+        h.local = h.normal = mk(0, 0, 0);
+        st.overflow = false;
+        if (live) trace_stage<false>(sv, o, d, n_shadow, st, h, nullptr);
+        // primary-hit ids come from the un-offset pixel-centre ray (sub-sample 4 of the 3x3 SSAA grid)
+        if (live && level == 0 && w.id_shape && i / fp.n_pix_slots == (fp.aa ? 4u : 0u)) {
+            w.id_shape[i % fp.n_pix_slots] = h.shape;
+            w.id_tri[i % fp.n_pix_slots] = h.tri;
+        }
+        shade_and_spawn<false>(sv, fp, w, tabs, sh, level, live, i, h, d, shadow_total, spawn_total);
+    }
+}
+
 // Stage 2 of a level for the rays that went through a hit record: LIST = true, the hard rays of the BVH
-// path (traced by k_trace_quad / the redo kernel); LIST = false, every ray of the level (accel = 1, where
+// path (traced by k_trace_quad / k_trace_coop); LIST = false, every ray of the level (accel = 1, where
 // k_trace does all the tracing).  The Perlin tables (256 B each) are staged in LDS: their chained lookups
 // are the latency chain of every sky / marble sample.
+// The redo list of the BVH path is re-traced and shaded by k_redo, launched behind this kernel.  (For most of round 3 the first
+// workgroups of k_shade<true> did that themselves, to save four launches on a frame's chain for a list that is almost always empty;
+// but the pass's kd walk then shares this kernel's register allocation - 128 VGPRs: 191 spilled instead of 35 - and the common path
+// paid for it: 32-frame calls 1.2 - 2.3 %, while a lone frame and a rank's eighth of a burst do not notice the launches:
+// profiles/r03_redo_split.txt.)
 template <bool LIST>
 __global__ __launch_bounds__(kBlock, RT_SHADE_OCC) void k_shade(SceneView sv, FrameParams fp, Work w, uint32_t level, uint32_t n_tables,
                                                                  uint32_t levels, uint32_t stack_cap) {
@@ -1613,56 +1658,26 @@ __global__ __launch_bounds__(kBlock, RT_SHADE_OCC) void k_shade(SceneView sv, Fr
         h.local = mk(hs.lx, hs.ly, hs.lz);
         h.normal = mk(hs.nx, hs.ny, hs.nz);
         V3 d = mk(0, 0, 1);
-        const bool have = hs.shape >= -1;  // (not: no ray in the slot, or a ray the redo pass below traces and shades)
+        const bool have = hs.shape >= -1;  // (not: no ray in the slot, or a ray the redo pass traces and shades)
         if (have) {
             const RayRec rr = ray_at(w, level, i);
             d = mk(rr.dx, rr.dy, rr.dz);
         }
         shade_and_spawn<false>(sv, fp, w, tabs, sh, level, have, i, h, d, shadow_total, spawn_total);
     }
-    // The redo list (rays only the reference kd-tree reproduces: kd-degenerate (ray, mesh) pairs and exact distance ties; normally
-    // empty): re-traced one ray per lane through every query (rtc::trace_stage) and shaded on the spot, by the first workgroups of
-    // this kernel - as a kernel of its own it was four launches of ~5 us on every frame's chain for a list that is almost always
-    // empty.  Stacks in global memory (w.redo_stack): the rare path takes no LDS from the common one.
-    if (LIST) {
-        const uint32_t n_redo = min(w.N, w.redo_count[0]);
-        const uint32_t busy = min(min(gridDim.x, kRedoBlocks), (n + kBlock - 1) / kBlock);  // workgroups that got here and take part
-        if (n_redo && blockIdx.x < busy) {  // (workgroup-uniform)
-            KdStack st = make_stack(w.redo_stack + (size_t)blockIdx.x * kBlock + threadIdx.x, kRedoBlocks * kBlock, stack_cap, nullptr);
-            const uint32_t n_shadow = fp.renderer == RTHIP_RENDER_RAYTRACER ? sv.n_lights : 0u;
-            it = 0;
-            for (uint32_t base = blockIdx.x * kBlock; base < n_redo; base += busy * kBlock) {
-                {   // Interrupt(): EVERY iteration - one of them is 256 rays through the reference's kd walk (on a height field seen along
-                    // its grid lines the pass takes milliseconds on its 64 workgroups; polled every eighth iteration it never looked again)
-                    if (threadIdx.x == 0) sh.irq = irq_load(w);
-                    __syncthreads();
-                    if (sh.irq) break;
-                }
-                const uint32_t j = base + threadIdx.x;
-                const bool live = j < n_redo;
-                const uint32_t i = live ? w.redo[j] : 0u;
-                V3 o = mk(0, 0, 0), d = mk(0, 0, 1);
-                if (live) {  // (level 0 too: k_trace_easy stored the primary rays it listed)
-                    const RayRec r = ray_at(w, level, i);
-                    o = mk(r.ox, r.oy, r.oz);
-                    d = mk(r.dx, r.dy, r.dz);
-                }
-                HitRec h;
-                h.shape = -1;
-                h.tri = -1;
-                h.shadow_mask = 0;
-                h.local = h.normal = mk(0, 0, 0);
-                st.overflow = false;
-                if (live) trace_stage<false>(sv, o, d, n_shadow, st, h, nullptr);
-                // primary-hit ids come from the un-offset pixel-centre ray (sub-sample 4 of the 3x3 SSAA grid)
-                if (live && level == 0 && w.id_shape && i / fp.n_pix_slots == (fp.aa ? 4u : 0u)) {
-                    w.id_shape[i % fp.n_pix_slots] = h.shape;
-                    w.id_tri[i % fp.n_pix_slots] = h.tri;
-                }
-                shade_and_spawn<false>(sv, fp, w, tabs, sh, level, live, i, h, d, shadow_total, spawn_total);
-            }
-        }
-    }
+    shade_stats_flush(w, sh, 1, level, levels, shadow_total, spawn_total);
+}
+// the redo pass, behind k_shade<true> (at most kRedoBlocks workgroups; their statistics go to the slots k_shade's workgroups of the
+// same index have just written)
+__global__ __launch_bounds__(kBlock) void k_redo(SceneView sv, FrameParams fp, Work w, uint32_t level, uint32_t n_tables, uint32_t levels,
+                                                 uint32_t stack_cap) {
+    __shared__ ShadeShared sh;
+    const uint32_t n_redo = min(w.N, w.redo_count[0]);
+    if (!n_redo) return;
+    const uint8_t *tabs = reinterpret_cast<const uint8_t *>(lds_dyn);
+    stage_perlin_tables(sv, n_tables);
+    uint32_t shadow_total = 0, spawn_total = 0;
+    redo_pass(sv, fp, w, tabs, sh, level, stack_cap, n_redo, gridDim.x, shadow_total, spawn_total);
     shade_stats_flush(w, sh, 1, level, levels, shadow_total, spawn_total);
 }
 
@@ -2831,8 +2846,10 @@ static int render_frame(rthip_ctx *c, const rthip_camera *cam, uint32_t n_frames
                 if (profile) HIP_TRY(hipEventRecord(eb, c->stream));
             }
             if (p->accel == 0) {
-                if (c->has_meshes)
+                if (c->has_meshes) {
                     hipLaunchKernelGGL((k_shade<true>), dim3(grid), dim3(kBlock), lds_tables, c->stream, c->sv, fp, w, level, c->n_tables, levels, c->stack_cap);
+                    hipLaunchKernelGGL(k_redo, dim3(grid < kRedoBlocks ? grid : kRedoBlocks), dim3(kBlock), lds_tables, c->stream, c->sv, fp, w, level, c->n_tables, levels, c->stack_cap);
+                }
             } else {
                 hipLaunchKernelGGL((k_shade<false>), dim3(grid), dim3(kBlock), lds_tables, c->stream, c->sv, fp, w, level, c->n_tables, levels, c->stack_cap);
             }

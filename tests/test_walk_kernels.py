@@ -241,3 +241,23 @@ def test_directional_lights_local_directions_from_the_upload_table(monkeypatch, 
         ref = sd.build(oracle_lib).render(96, 64, ids=True, threads=8, max_recursion=3)
         for mode in ("quad", "coop64"):
             _same(_render(monkeypatch, mode, sd, 96, 64, max_recursion=3), ref, f"table {table} {mode} fuzz {seed}")
+
+
+def test_redo_pass_behind_k_shade(monkeypatch, oracle_lib):
+    """The redo list (exact ties, rays in a kd split plane) is re-traced and shaded by k_redo behind k_shade (rthip.hip): with
+    every walk kernel in front of it, with SSAA (ids come from sub-sample 4 only), and on the edge scenes."""
+    sd, _ = tie_scene(2)
+    ref = sd.build(oracle_lib).render(64, 48, ids=True, threads=4, max_recursion=2)
+    for mode in ("quad", "coop64", "default"):
+        _same(_render(monkeypatch, mode, sd, 64, 48, max_recursion=2), ref, f"{mode} ties")
+    sd = scenes.SceneDesc("grid mesh symmetric about x = 0, camera on the plane x = 0")
+    m = sd.uniform_material(0x88aa66, 0.8)
+    v, n = scenes.heightfield_mesh(cells=32, seed=5, extent=4.0)
+    sd.mesh(m, v, n, scenes.NORMAL_VERTEX)
+    sd.directional_light(0xffffff, 1, 2, 1)
+    sd.color_background(0x102030)
+    sd.look_at((0, 5, 9), (0, 0, 0))
+    for kw in (dict(max_recursion=2), dict(max_recursion=1, aa=1)):
+        ref = sd.build(oracle_lib).render(128, 96, ids=True, threads=8, **kw)
+        for mode in ("quad", "coop32"):
+            _same(_render(monkeypatch, mode, sd, 128, 96, **kw), ref, f"{mode} kd-plane rays {kw}")
