@@ -300,29 +300,31 @@ RT_HD double noise_wrap(double x, double domain) {
     x = (double)fmodf_exact((float)x, (float)domain) / domain;
     return x < 0 ? 1.0 + x : x;
 }
+// LEAN (here and in material_eval / shade_stage / debug_shade): the instantiation for scenes whose shapes' materials are uniform
+// or ONE interpolation of two uniform ones by a checker board or Perlin noise (rthip.hip: lean_scene decides at upload; the demo
+// scenes with a ground plane and plain objects).  Worley's 27-cell loop, Marble's sin() (~900 instructions of argument reduction)
+// and the material stack are then not part of the kernel, whose register allocation they dominate although such a scene never runs
+// them: k_trace_easy spills 7 registers instead of 61, k_shade none instead of 26 (profiles/r03_lean_kernels.txt).
+template <bool LEAN = false>
 RT_HD double noise_sample(const SceneView &sv, const uint8_t *tabs, int32_t ni, V3 p) {
     const rthip_noise &n = sv.noises[ni];
     V3 q = mk(noise_wrap(p.x, n.domain), noise_wrap(p.y, n.domain), noise_wrap(p.z, n.domain));
-    switch (n.type) {
-    case RTHIP_NOISE_CHECKER: {  // CheckerBoard.cpp:3-16
+    if (n.type == RTHIP_NOISE_CHECKER) {  // CheckerBoard.cpp:3-16
         int t0 = q.x <= 0.5, t2 = q.z <= 0.5;
         return (double)(t2 ^ t0);
     }
-    case RTHIP_NOISE_PERLIN:
-        return perlin_normalized(tabs + 256 * (size_t)n.table, n.octaves, n.persistance, q);
-    case RTHIP_NOISE_WORLEY:
-        return worley_normalized(sv.worley_points + 3 * (size_t)n.points_base, n.divisions, n.step, q);
-    default: {  // Marble.cpp:11-15
-        double f = perlin_normalized(tabs + 256 * (size_t)n.table, n.octaves, n.persistance, q) * n.turbolence;
-        return fabs(sin(f * n.frequency * (double)3.141592f));
-    }
-    }
+    if (LEAN || n.type == RTHIP_NOISE_PERLIN) return perlin_normalized(tabs + 256 * (size_t)n.table, n.octaves, n.persistance, q);
+    if (n.type == RTHIP_NOISE_WORLEY) return worley_normalized(sv.worley_points + 3 * (size_t)n.points_base, n.divisions, n.step, q);
+    // Marble.cpp:11-15
+    double f = perlin_normalized(tabs + 256 * (size_t)n.table, n.octaves, n.persistance, q) * n.turbolence;
+    return fabs(sin(f * n.frequency * (double)3.141592f));
 }
 
 // ----------------------------------------------------------------------------- materials (M1, M2)
 // Evaluates the postfix program ending at op `root`: Lerp<Color> = a*(1-t) (+) b*t with clamping
 // Color ops, Lerp<real> unclamped (Material.cpp:21-29).  Noise is sampled once per INTERP node
 // (the reference re-samples it per query; Sample is a pure function of the point).
+template <bool LEAN = false>
 RT_HD void material_eval(const SceneView &sv, const uint8_t *tabs, int32_t root, V3 p, Col &color, double &absorptance) {
     const rthip_matop &r = sv.materials[root];
     if (r.op == RTHIP_MAT_UNIFORM) {
@@ -330,9 +332,9 @@ RT_HD void material_eval(const SceneView &sv, const uint8_t *tabs, int32_t root,
         absorptance = r.absorptance;
         return;
     }
-    if (root - r.first_op == 2) {  // INTERP of two UNIFORMs: no stack needed
+    if (LEAN || root - r.first_op == 2) {  // INTERP of two UNIFORMs: no stack needed
         const rthip_matop &a = sv.materials[root - 2], &b = sv.materials[root - 1];
-        double t = noise_sample(sv, tabs, r.noise, p);
+        double t = noise_sample<LEAN>(sv, tabs, r.noise, p);
         color = c_add(c_scale(c_from(a.color), 1 - t), c_scale(c_from(b.color), t));
         absorptance = lerp(a.absorptance, b.absorptance, t);
         return;
@@ -1275,6 +1277,7 @@ struct ShadeOut {
     uint32_t shadow_rays;  // CastShadowRay calls the reference makes for this hit
 };
 
+template <bool LEAN = false>
 RT_HD void shade_stage(const SceneView &sv, const uint8_t *tabs, const HitRec &h, V3 rd, bool may_reflect, ShadeOut &out) {
     out.spawn = false;
     out.refl = 0.0;
@@ -1288,7 +1291,7 @@ RT_HD void shade_stage(const SceneView &sv, const uint8_t *tabs, const HitRec &h
     V3 point = xform(sh.fwd, h.local, 1.0);  // worldPoint, recomputed exactly as Scene.cpp:196
     Col albedo;
     double absorptance;
-    material_eval(sv, tabs, sh.material, h.local, albedo, absorptance);
+    material_eval<LEAN>(sv, tabs, sh.material, h.local, albedo, absorptance);
     double reflectance = 1.0 - absorptance;  // Material.cpp:9-12
     Col direct = Col{0, 0, 0};
     if (absorptance > 0) {
@@ -1388,6 +1391,7 @@ RT_HD Col raycast(const SceneView &sv, V3 o, V3 d, uint32_t max_recursion, KdSta
 
 // DebugRaycaster::Raycast (Raytracer.cpp:317-351); mode 0 Normal, 1 Color: shading half (the query half is a
 // closest-hit cast_ray)
+template <bool LEAN = false>
 RT_HD Col debug_shade(const SceneView &sv, const uint8_t *tabs, const HitRec &h, V3 d, int mode) {
     if (mode == 0) {
         if (h.shape >= 0) return mkc((h.normal.x + 1) / 2, (h.normal.y + 1) / 2, 1 - (h.normal.z + 1) / 2);
@@ -1396,7 +1400,7 @@ RT_HD Col debug_shade(const SceneView &sv, const uint8_t *tabs, const HitRec &h,
     if (h.shape >= 0) {
         Col albedo;
         double a;
-        material_eval(sv, tabs, sv.shapes[h.shape].material, h.local, albedo, a);
+        material_eval<LEAN>(sv, tabs, sv.shapes[h.shape].material, h.local, albedo, a);
         return albedo;
     }
     return background_color(sv, tabs, d);

@@ -872,7 +872,7 @@ struct ShadeShared {
     uint32_t part[2][kBlock / 64];
     uint32_t irq;  // Work::irq as thread 0 read it: the whole workgroup leaves together (its iterations contain barriers)
 };
-template <bool HARD>
+template <bool HARD, bool LEAN = false>
 __device__ __forceinline__ void shade_and_spawn(const SceneView &sv, const FrameParams &fp, const Work &w, const uint8_t *tabs,
                                                 ShadeShared &sh, uint32_t level, bool have, uint32_t i, const HitRec &h, V3 d,
                                                 uint32_t &shadow_total, uint32_t &spawn_total, bool is_hard = false,
@@ -883,9 +883,9 @@ __device__ __forceinline__ void shade_and_spawn(const SceneView &sv, const Frame
     so.shadow_rays = 0;
     if (have) {
         if (fp.renderer == RTHIP_RENDER_RAYTRACER) {
-            shade_stage(sv, tabs, h, d, level < fp.max_rec, so);
+            shade_stage<LEAN>(sv, tabs, h, d, level < fp.max_rec, so);
         } else {
-            so.color = debug_shade(sv, tabs, h, d, fp.renderer - 1);
+            so.color = debug_shade<LEAN>(sv, tabs, h, d, fp.renderer - 1);
             so.refl = 0.0;
         }
         ColRec cr;
@@ -1121,7 +1121,8 @@ __device__ __forceinline__ bool trace_stage(const SceneView &sv, V3 o, V3 d, uin
 
 // Also stage 2 for the rays it finishes: they are shaded on the spot (no hit record leaves the
 // registers) and their reflected rays go straight to the next level's queue.
-template <bool COUNT>
+// LEAN: the scene's materials need neither Worley / Marble noise nor the material stack (rtc::noise_sample)
+template <bool COUNT, bool LEAN = false>
 __global__ __launch_bounds__(kBlock, RT_EASY_OCC) void k_trace_easy(SceneView sv, FrameParams fp, Work w, uint32_t level,
                                                                       uint32_t n_tables, uint32_t levels) {
     __shared__ ShadeShared sh;
@@ -1165,7 +1166,7 @@ __global__ __launch_bounds__(kBlock, RT_EASY_OCC) void k_trace_easy(SceneView sv
             w.id_shape[pix_slot] = h.shape;
             w.id_tri[pix_slot] = -1;
         }
-        shade_and_spawn<true>(sv, fp, w, tabs, sh, level, live && done, i, h, d, shadow_total, spawn_total, is_hard, &analytic, o);
+        shade_and_spawn<true, LEAN>(sv, fp, w, tabs, sh, level, live && done, i, h, d, shadow_total, spawn_total, is_hard, &analytic, o);
     }
     shade_stats_flush(w, sh, 0, level, levels, shadow_total, spawn_total);
     if (COUNT) {
@@ -1626,7 +1627,7 @@ __device__ __forceinline__ void redo_pass(const SceneView &sv, const FrameParams
 // but the pass's kd walk then shares this kernel's register allocation - 128 VGPRs: 191 spilled instead of 35 - and the common path
 // paid for it: 32-frame calls 1.2 - 2.3 %, while a lone frame and a rank's eighth of a burst do not notice the launches:
 // profiles/r03_redo_split.txt.)
-template <bool LIST>
+template <bool LIST, bool LEAN = false>
 __global__ __launch_bounds__(kBlock, RT_SHADE_OCC) void k_shade(SceneView sv, FrameParams fp, Work w, uint32_t level, uint32_t n_tables,
                                                                  uint32_t levels, uint32_t stack_cap) {
     __shared__ ShadeShared sh;
@@ -1663,7 +1664,7 @@ __global__ __launch_bounds__(kBlock, RT_SHADE_OCC) void k_shade(SceneView sv, Fr
             const RayRec rr = ray_at(w, level, i);
             d = mk(rr.dx, rr.dy, rr.dz);
         }
-        shade_and_spawn<false>(sv, fp, w, tabs, sh, level, have, i, h, d, shadow_total, spawn_total);
+        shade_and_spawn<false, LEAN>(sv, fp, w, tabs, sh, level, have, i, h, d, shadow_total, spawn_total);
     }
     shade_stats_flush(w, sh, 1, level, levels, shadow_total, spawn_total);
 }
@@ -1884,6 +1885,7 @@ struct rthip_ctx {
     // frame workspace
     DevBuf rec, child, rays, counts, stats, block_stats, ids, pixels_tmp, ids_out, hits, redo, redo_stack, pend, probe[8];
     DevBuf shadow_ld;  // SceneView::shadow_ld
+    bool lean_scene = false;  // every shape's material is uniform or one checker / Perlin interpolation of two uniform ones: the LEAN kernels
     uint32_t bs_stride = 0, bs_levels = 0;
     uint32_t n_tables = 0;
     bool has_meshes = false;
@@ -2483,6 +2485,20 @@ static int upload_scene_impl(rthip_ctx *c, const rthip_scene_desc *s, bool keep_
         }
     }
     c->n_tables = s->n_perlin_tables;
+    {   // the LEAN instantiations of k_trace_easy / k_shade (rtc::noise_sample); RTHIP_LEAN=0: never
+        const char *env = getenv("RTHIP_LEAN");  // (read at every upload: tests compare the two)
+        bool lean = !(env && atoi(env) == 0);
+        for (uint32_t i = 0; lean && i < s->n_shapes; i++) {
+            const int32_t root = s->shapes[i].material;
+            if (root < 0 || (uint32_t)root >= s->n_materials) { lean = false; break; }
+            const rthip_matop &r = s->materials[root];
+            if (r.op == RTHIP_MAT_UNIFORM) continue;
+            lean = root - r.first_op == 2 && root >= 2 && s->materials[root - 2].op == RTHIP_MAT_UNIFORM && s->materials[root - 1].op == RTHIP_MAT_UNIFORM &&
+                   r.noise >= 0 && (uint32_t)r.noise < s->n_noises &&
+                   (s->noises[r.noise].type == RTHIP_NOISE_CHECKER || s->noises[r.noise].type == RTHIP_NOISE_PERLIN);
+        }
+        c->lean_scene = lean;
+    }
     c->has_meshes = s->n_meshes > 0;
     c->mesh_without_bvh = -1;
     for (uint32_t i = 0; i < s->n_meshes; i++)
@@ -2808,6 +2824,8 @@ static int render_frame(rthip_ctx *c, const rthip_camera *cam, uint32_t n_frames
             if (p->accel == 0) {
                 if (c->count_kd)
                     hipLaunchKernelGGL((k_trace_easy<true>), dim3(grid), dim3(kBlock), lds_tables, c->stream, c->sv, fp, w, level, c->n_tables, levels);
+                else if (c->lean_scene)
+                    hipLaunchKernelGGL((k_trace_easy<false, true>), dim3(grid), dim3(kBlock), lds_tables, c->stream, c->sv, fp, w, level, c->n_tables, levels);
                 else
                     hipLaunchKernelGGL((k_trace_easy<false>), dim3(grid), dim3(kBlock), lds_tables, c->stream, c->sv, fp, w, level, c->n_tables, levels);
                 if (profile) HIP_TRY(hipEventRecord(eq, c->stream));
@@ -2847,7 +2865,10 @@ static int render_frame(rthip_ctx *c, const rthip_camera *cam, uint32_t n_frames
             }
             if (p->accel == 0) {
                 if (c->has_meshes) {
-                    hipLaunchKernelGGL((k_shade<true>), dim3(grid), dim3(kBlock), lds_tables, c->stream, c->sv, fp, w, level, c->n_tables, levels, c->stack_cap);
+                    if (c->lean_scene && !c->count_kd)
+                        hipLaunchKernelGGL((k_shade<true, true>), dim3(grid), dim3(kBlock), lds_tables, c->stream, c->sv, fp, w, level, c->n_tables, levels, c->stack_cap);
+                    else
+                        hipLaunchKernelGGL((k_shade<true>), dim3(grid), dim3(kBlock), lds_tables, c->stream, c->sv, fp, w, level, c->n_tables, levels, c->stack_cap);
                     hipLaunchKernelGGL(k_redo, dim3(grid < kRedoBlocks ? grid : kRedoBlocks), dim3(kBlock), lds_tables, c->stream, c->sv, fp, w, level, c->n_tables, levels, c->stack_cap);
                 }
             } else {

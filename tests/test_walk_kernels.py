@@ -261,3 +261,33 @@ def test_redo_pass_behind_k_shade(monkeypatch, oracle_lib):
         ref = sd.build(oracle_lib).render(128, 96, ids=True, threads=8, **kw)
         for mode in ("quad", "coop32"):
             _same(_render(monkeypatch, mode, sd, 128, 96, **kw), ref, f"{mode} kd-plane rays {kw}")
+
+
+@pytest.mark.parametrize("lean", ["0", "1"])
+def test_lean_kernels_for_scenes_without_worley_marble_or_material_stacks(monkeypatch, oracle_lib, lean):
+    """k_trace_easy / k_shade have a second instantiation without Worley's cell loop, Marble's sin() and the material stack
+    (rt_core.hpp: noise_sample<LEAN>), picked at upload for scenes whose shapes' materials are uniform or one checker / Perlin
+    interpolation of two uniform ones (rthip.hip: lean_scene; RTHIP_LEAN=0: never).  Such scenes give the oracle's frames through
+    either; a scene that needs the full kernels (Demo 1: marble, Worley, a nested interpolation) must not be mistaken for one."""
+    monkeypatch.setenv("RTHIP_LEAN", lean)   # (read when the scene is uploaded)
+    for n, w, h, kw in ((1, 96, 72, dict(max_recursion=1)), (3, 160, 90, dict(max_recursion=3)), (3, 96, 54, dict(max_recursion=2, aa=1)),
+                        (2, 128, 72, dict(max_recursion=3))):
+        sd = scenes.config(n)[0]
+        ref = sd.build(oracle_lib).render(w, h, ids=True, threads=8, **kw)
+        _same(_render(monkeypatch, "default", sd, w, h, **kw), ref, f"lean {lean} config {n} {kw}")
+    sd = scenes.config(5, cells=16)[0]
+    ref = sd.build(oracle_lib).render(128, 72, ids=True, threads=8, max_recursion=5)
+    for mode in ("quad", "coop64"):
+        _same(_render(monkeypatch, mode, sd, 128, 72, max_recursion=5), ref, f"lean {lean} {mode} config 5")
+    # a Perlin-interpolated material (lean) next to the debug renderers, which evaluate materials too
+    sd = scenes.SceneDesc("perlin-interpolated sphere over a checker plane")
+    a = sd.uniform_material(0x224488, 0.7)
+    b = sd.uniform_material(0xffeedd, 0.2)
+    sd.position(0, 0.5, 0); sd.sphere(sd.interpolated_material(sd.perlin(2, seed=77), a, b))
+    sd.position(0, -1, 0); sd.plane(sd.interpolated_material(sd.checker(2), a, b), 0, 1, 0)
+    sun = sd.directional_light(0xffffff, 1, 2, 1)
+    sd.skybox(0x4444ff, 0xffffff, sun, seed=78)
+    sd.look_at((0, 2, 5), (0, 0, 0))
+    for kw in (dict(max_recursion=3), dict(max_recursion=0, renderer=2), dict(max_recursion=0, renderer=1)):
+        ref = sd.build(oracle_lib).render(96, 64, ids=True, threads=4, **kw)
+        _same(_render(monkeypatch, "default", sd, 96, 64, **kw), ref, f"lean {lean} perlin material {kw}")
