@@ -55,9 +55,9 @@ def _newest(*names):
     return os.path.join("profiles", names[0])
 
 
-PMC_CFG3 = _newest("r03f_pmc_summary_config3_batch32.json", "r03e_pmc_summary_config3_batch32.json", "r03_pmc_summary_config3_batch32.json", "r03_pmc_summary_config3_batch8.json", "r02_pmc_summary_config3_batch8.json")
-PMC_CFG4 = _newest("r03f_pmc_summary_config4.json", "r03e_pmc_summary_config4.json", "r03_pmc_summary_config4.json", "r02_pmc_summary_config4.json")
-PMC_CFG5 = _newest("r03f_pmc_summary_config5.json", "r03_pmc_summary_config5.json")
+PMC_CFG3 = _newest("r03g_pmc_summary_config3_batch32.json", "r03f_pmc_summary_config3_batch32.json", "r03e_pmc_summary_config3_batch32.json", "r03_pmc_summary_config3_batch32.json", "r03_pmc_summary_config3_batch8.json", "r02_pmc_summary_config3_batch8.json")
+PMC_CFG4 = _newest("r03g_pmc_summary_config4.json", "r03f_pmc_summary_config4.json", "r03e_pmc_summary_config4.json", "r03_pmc_summary_config4.json", "r02_pmc_summary_config4.json")
+PMC_CFG5 = _newest("r03g_pmc_summary_config5.json", "r03f_pmc_summary_config5.json", "r03_pmc_summary_config5.json")
 
 # ALGORITHMIC flops of the dominant kernel (SURVEY.md §8d "ALGORITHMIC flops per ray": fixed weights x measured counts), for
 # k_trace_quad's units of work:
