@@ -14,8 +14,11 @@
 //                      wave, one ray per lane for whatever is per-ray work (transforms, hit record, shadow set-up,
 //                      analytic shadow casters), the mesh walks 16 rays at a time through quad::mesh_closest.
 //                      (Which of the two a level launches: render_frame, walk_mode.)
-//   k_shade<true>    : shading + spawn of the listed rays from their hit records; its first workgroups re-trace
-//                      the redo list (rays only the reference kd-tree reproduces; normally empty).
+//   k_shade<true>    : shading + spawn of the listed rays from their hit records.
+//   k_redo           : re-traces and shades the redo list (rays only the reference kd-tree reproduces; normally empty).
+// k_trace_easy and k_shade have a LEAN instantiation for scenes whose materials need neither Worley / Marble noise nor the
+// material stack (upload_scene: lean_scene).  What is the same for every ray is computed once at upload (k_light_dirs: the
+// directional lights' directions in every shape's frame, the planes' world normals).
 // then k_resolve: per pixel, C_k = direct_k (+) C_{k+1} (x) refl_k folded back to front along the pixel's
 // chain of rays (clamping Color algebra forbids a forward throughput product), 3x3 SSAA
 // sum, 0xAABBGGRR pack.  accel = 1 runs k_trace<false,.> + k_shade<false> instead (reference kd-tree,
